@@ -1,0 +1,24 @@
+// ctx.h — the opaque context behind chase_hip_ctx* (include/chase_hip.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+struct chase_hip_ctx {
+    int device = 0;
+    int num_cu = 0;
+    int clock_khz = 0;
+    size_t hbm_bytes = 0;
+    char name[128] = {0};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void* ws = nullptr;          // split-K slabs / scratch, grown on demand
+    size_t ws_bytes = 0;
+
+    int ensure_ws(size_t bytes);
+};
+
+namespace chase_hip {
+int set_error(int code, const char* what);
+int hip_fail(hipError_t e, const char* where);
+}

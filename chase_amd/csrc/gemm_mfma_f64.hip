@@ -1,0 +1,467 @@
+// gemm_mfma_f64.hip — fp64 / complex-fp64 panel GEMM for gfx950 (MI355X, CDNA4)
+//
+//   C[m x n] = alpha * op(A) * B + beta * C        column-major, op in {N, C}
+//
+// This is the kernel behind every dense product of the ChASE hot path:
+//   * Chebyshev-filter HEMM      V2 = a*(H-cI)*V1 + b*V2   (reference: Impl/chase_cpu/chase_cpu.hpp:449-508,
+//                                                            Impl/chase_gpu/chase_gpu.hpp:656-678 -> cublasTgemm N,N)
+//   * distributed HEMM           W = a*H_loc^H*V + b*W      (reference: linalg/internal/mpi/hemm.hpp:114-229 -> gemm C,N / N,N)
+//   * Gram / projection products A = V^H*V, A = W^H*Q       (reference: linalg/internal/cpu/cholqr1.hpp:41 (herk),
+//                                                            linalg/internal/cpu/rayleighRitz.hpp:84-88)
+//   * back-transform             V = Q*A                    (reference: linalg/internal/cpu/rayleighRitz.hpp:110)
+//
+// Design (MI355X-first, not a translation of any CUDA tiling):
+//   * v_mfma_f64_16x16x4_f64, one 64-lane wave owns a (16*TM) x (16*TN) output tile, 4 waves (2x2) per workgroup.
+//     MFMA operand roles are swapped (first operand = B/V fragment, second = A/H fragment) so that the accumulator's
+//     lane index runs along the column-major M direction -> 256-byte contiguous C stores per 16 lanes.
+//   * Everything in LDS is addressed in 16-byte "units" so that every fragment fetch is one ds_read_b128 and the
+//     16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots (conflict-free without padding):
+//       - real,    M-contiguous operand (A, op=N): unit = rows (2r, 2r+1) at one k  -> feeds two M tiles at once
+//       - real,    K-contiguous operand (B; A op=C): unit = k (2q, 2q+1) of one row -> feeds two consecutive MFMAs
+//       - complex: unit = one (re, im) element
+//     The K order inside an 8-deep (real) chunk is permuted (MFMA s takes k = 2q+s) identically for both operands.
+//   * K-contiguous tiles are stored [k-unit][row ^ k-unit] (XOR on the low 3 bits) so that the staging ds_write_b128
+//     and the fragment ds_read_b128 are both conflict-free.
+//   * complex: 4 real MFMAs per (re,im) tile step on planar fragments held in registers (interleaved in HBM/LDS).
+//   * global -> register -> LDS staging, double-buffered LDS, one barrier per K step, two workgroups per CU.
+//   * XCD-aware tile order: consecutive logical tiles (same A row panel, different column panels) run on one XCD
+//     so the streamed H panel is fetched once per XCD L2.
+//   * deterministic split-K (slabs + fixed-order reduce) for the short-and-fat Gram products (k = N >> m, n).
+//
+// No vendor BLAS, no CUDA headers.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+namespace chase_hip {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef d2_t d2u_t __attribute__((aligned(8)));   // 16-byte vector that may sit on an 8-byte boundary in HBM
+
+template <bool CPLX, bool OPA_C>
+struct Cfg {
+    static constexpr int NTHREADS = 256;
+    static constexpr int WAVES_M = 2, WAVES_N = 2;
+    static constexpr int TM = 4;                    // 16-row MFMA tiles per wave along M
+    static constexpr int TN = CPLX ? 2 : 4;         // 16-col MFMA tiles per wave along N
+    static constexpr int BM = 16 * TM * WAVES_M;    // 128
+    static constexpr int BN = 16 * TN * WAVES_N;    // 128 (real) / 64 (complex)
+    static constexpr int BK = CPLX ? 8 : 16;        // elements of T along K per stage
+    static constexpr int KPU = CPLX ? 1 : 2;        // k per 16-byte unit of a K-contiguous operand
+    static constexpr int RPU = CPLX ? 1 : 2;        // rows per 16-byte unit of an M-contiguous operand
+    static constexpr int A_UNITS = OPA_C ? BM * 8 : BK * (BM / RPU);   // 1024 in all variants
+    static constexpr int B_UNITS = BN * 8;                              // 1024 real / 512 complex
+    static constexpr int A_PASSES = A_UNITS / NTHREADS;
+    static constexpr int B_PASSES = B_UNITS / NTHREADS;
+    static constexpr int STAGE_UNITS = A_UNITS + B_UNITS;
+    static constexpr int EPT = CPLX ? 2 : 1;        // doubles per element
+};
+
+// bijective XCD remap (blocks b and b+8 share an XCD): gives each XCD a contiguous range of logical tiles
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
+{
+    const unsigned q = nblk >> 3, r = nblk & 7u, x = b & 7u;
+    const unsigned base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (b >> 3);
+}
+
+struct GemmArgs {
+    const double* A; const double* B; double* C;     // C may point to split-K slabs
+    long lda, ldb, ldc;                              // in elements of T
+    int m, n, k;
+    int gm, gn, splitk, kchunk;                      // grid decomposition; kchunk multiple of BK
+    double alpha_re, alpha_im, beta_re, beta_im;
+    long slab_stride;                                // elements of T between split-K slabs (0 if splitk == 1)
+};
+
+template <bool CPLX, bool OPA_C>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
+{
+    using C_ = Cfg<CPLX, OPA_C>;
+    constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TM = C_::TM, TN = C_::TN;
+    constexpr int EPT = C_::EPT, KPU = C_::KPU, RPU = C_::RPU;
+    constexpr int UM = BM / RPU;                    // units per k-column of an M-contiguous A tile
+
+    extern __shared__ __attribute__((aligned(16))) d2_t lds[];   // [2][STAGE_UNITS]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;        // wave position in the 2x2 grid
+    const int c16 = lane & 15, q = lane >> 4;
+
+    // ---- logical tile -------------------------------------------------------------------------------------------
+    const unsigned nblk = gridDim.x;
+    unsigned L = xcd_remap(blockIdx.x, nblk);
+    const int bn = L % p.gn; L /= p.gn;
+    const int bm = L % p.gm; L /= p.gm;
+    const int bz = L;                               // split-K slice
+    const int row0 = bm * BM, col0 = bn * BN;
+    const int kbeg = bz * p.kchunk;
+    const int kend = min(p.k, kbeg + p.kchunk);
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+
+    const bool interior = (row0 + BM <= p.m) && (col0 + BN <= p.n);
+
+    // ---- staging registers --------------------------------------------------------------------------------------
+    d2_t ra[C_::A_PASSES], rb[C_::B_PASSES];
+
+    auto load_tile = [&](int k0) {
+        const bool kfull = (k0 + BK <= kend);
+        if (interior && kfull) {
+            #pragma unroll
+            for (int ps = 0; ps < C_::A_PASSES; ++ps) {
+                const int idx = ps * 256 + tid;
+                if constexpr (!OPA_C) {
+                    const int kk = idx / UM, u = idx % UM;
+                    const double* g = p.A + ((long)(k0 + kk) * p.lda + row0 + u * RPU) * EPT;
+                    ra[ps] = *(const d2u_t*)g;
+                } else {
+                    const int r = idx >> 3, ku = idx & 7;
+                    const double* g = p.A + ((long)(row0 + r) * p.lda + k0 + ku * KPU) * EPT;
+                    ra[ps] = *(const d2u_t*)g;
+                }
+            }
+            #pragma unroll
+            for (int ps = 0; ps < C_::B_PASSES; ++ps) {
+                const int idx = ps * 256 + tid;
+                const int r = idx >> 3, ku = idx & 7;
+                const double* g = p.B + ((long)(col0 + r) * p.ldb + k0 + ku * KPU) * EPT;
+                rb[ps] = *(const d2u_t*)g;
+            }
+        } else {
+            #pragma unroll
+            for (int ps = 0; ps < C_::A_PASSES; ++ps) {
+                const int idx = ps * 256 + tid;
+                d2_t v = {0.0, 0.0};
+                if constexpr (!OPA_C) {
+                    const int kk = idx / UM, u = idx % UM;
+                    const int gi = row0 + u * RPU, gk = k0 + kk;
+                    if (gk < kend) {
+                        const double* g = p.A + ((long)gk * p.lda + gi) * EPT;
+                        if constexpr (CPLX) { if (gi < p.m) v = *(const d2u_t*)g; }
+                        else { if (gi < p.m) v.x = g[0]; if (gi + 1 < p.m) v.y = g[1]; }
+                    }
+                } else {
+                    const int r = idx >> 3, ku = idx & 7;
+                    const int gi = row0 + r, gk = k0 + ku * KPU;
+                    if (gi < p.m) {
+                        const double* g = p.A + ((long)gi * p.lda + gk) * EPT;
+                        if constexpr (CPLX) { if (gk < kend) v = *(const d2u_t*)g; }
+                        else { if (gk < kend) v.x = g[0]; if (gk + 1 < kend) v.y = g[1]; }
+                    }
+                }
+                ra[ps] = v;
+            }
+            #pragma unroll
+            for (int ps = 0; ps < C_::B_PASSES; ++ps) {
+                const int idx = ps * 256 + tid;
+                const int r = idx >> 3, ku = idx & 7;
+                const int gj = col0 + r, gk = k0 + ku * KPU;
+                d2_t v = {0.0, 0.0};
+                if (gj < p.n) {
+                    const double* g = p.B + ((long)gj * p.ldb + gk) * EPT;
+                    if constexpr (CPLX) { if (gk < kend) v = *(const d2u_t*)g; }
+                    else { if (gk < kend) v.x = g[0]; if (gk + 1 < kend) v.y = g[1]; }
+                }
+                rb[ps] = v;
+            }
+        }
+    };
+
+    auto store_tile = [&](int stage) {
+        d2_t* sA = lds + stage * C_::STAGE_UNITS;
+        d2_t* sB = sA + C_::A_UNITS;
+        #pragma unroll
+        for (int ps = 0; ps < C_::A_PASSES; ++ps) {
+            const int idx = ps * 256 + tid;
+            if constexpr (!OPA_C) {
+                sA[idx] = ra[ps];                                   // [k][unit], identical to the load order
+            } else {
+                const int r = idx >> 3, ku = idx & 7;
+                sA[ku * BM + (r ^ ku)] = ra[ps];
+            }
+        }
+        #pragma unroll
+        for (int ps = 0; ps < C_::B_PASSES; ++ps) {
+            const int idx = ps * 256 + tid;
+            const int r = idx >> 3, ku = idx & 7;
+            sB[ku * BN + (r ^ ku)] = rb[ps];
+        }
+    };
+
+    // ---- accumulators -------------------------------------------------------------------------------------------
+    d4_t acc[CPLX ? 2 : 1][TN][TM];
+    #pragma unroll
+    for (int z = 0; z < (CPLX ? 2 : 1); ++z)
+        #pragma unroll
+        for (int j = 0; j < TN; ++j)
+            #pragma unroll
+            for (int i = 0; i < TM; ++i) acc[z][j][i] = d4_t{0.0, 0.0, 0.0, 0.0};
+
+    const int wrow = wm * (16 * TM);                // wave's first row inside the block tile
+    const int wcol = wn * (16 * TN);
+
+    auto compute = [&](int stage) {
+        const d2_t* sA = lds + stage * C_::STAGE_UNITS;
+        const d2_t* sB = sA + C_::A_UNITS;
+        #pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {            // two 4-unit chunks along K per stage
+            const int ku = 4 * ch + q;
+            d2_t fb[TN];
+            #pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wcol + 16 * j + c16;
+                fb[j] = sB[ku * BN + (r ^ ku)];
+            }
+            if constexpr (!CPLX) {
+                // real: per chunk two MFMA k-steps s = 0,1 using k = 8*ch + 2*q + s
+                double fa[TM][2];                   // [tile][s]
+                if constexpr (OPA_C) {
+                    #pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int r = wrow + 16 * i + c16;
+                        const d2_t v = sA[ku * BM + (r ^ ku)];
+                        fa[i][0] = v.x; fa[i][1] = v.y;
+                    }
+                } else {
+                    #pragma unroll
+                    for (int pr = 0; pr < TM / 2; ++pr)
+                        #pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const int kk = 8 * ch + 2 * q + s;
+                            const d2_t v = sA[kk * UM + (wrow / 2) + 16 * pr + c16];   // rows (2u, 2u+1)
+                            fa[2 * pr][s] = v.x;
+                            fa[2 * pr + 1][s] = v.y;
+                        }
+                }
+                #pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    #pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        #pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                                s == 0 ? fb[j].x : fb[j].y, fa[i][s], acc[0][j][i], 0, 0, 0);
+            } else {
+                d2_t fa[TM];
+                #pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int r = wrow + 16 * i + c16;
+                    if constexpr (OPA_C) fa[i] = sA[ku * BM + (r ^ ku)];
+                    else                 fa[i] = sA[ku * UM + r];
+                }
+                // op=N: (ar + i ai)(br + i bi);  op=C: (ar - i ai)(br + i bi)
+                double ai_re[TM], ai_im[TM];
+                #pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ai_re[i] = OPA_C ? fa[i].y : -fa[i].y;         // multiplies bi into the real part
+                    ai_im[i] = OPA_C ? -fa[i].y : fa[i].y;         // multiplies br into the imaginary part
+                }
+                #pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    #pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].x, fa[i].x, acc[0][j][i], 0, 0, 0);
+                        acc[1][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].y, fa[i].x, acc[1][j][i], 0, 0, 0);
+                    }
+                #pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    #pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].y, ai_re[i], acc[0][j][i], 0, 0, 0);
+                        acc[1][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].x, ai_im[i], acc[1][j][i], 0, 0, 0);
+                    }
+            }
+        }
+    };
+
+    // ---- main loop ----------------------------------------------------------------------------------------------
+    if (nkt > 0) {
+        load_tile(kbeg);
+        store_tile(0);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nkt) load_tile(kbeg + (kt + 1) * BK);
+            compute(cur);
+            if (kt + 1 < nkt) store_tile(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------------------------
+    // accumulator element: D[row = q + 4g -> N index][col = c16 -> M index]
+    double* Cb = p.C + (long)bz * p.slab_stride * EPT;
+    const bool raw = (p.splitk > 1);                 // slabs get the unscaled partial sums
+    const double are = p.alpha_re, aim = p.alpha_im, bre = p.beta_re, bim = p.beta_im;
+    const bool has_beta = (bre != 0.0) || (bim != 0.0);
+
+    #pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        #pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int gj = col0 + wcol + 16 * j + q + 4 * g;
+            if (gj >= p.n) continue;
+            if constexpr (CPLX) {
+                #pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int gi = row0 + wrow + 16 * i + c16;
+                    if (gi >= p.m) continue;
+                    double* c = Cb + ((long)gj * p.ldc + gi) * 2;
+                    const double xr = acc[0][j][i][g], xi = acc[1][j][i][g];
+                    d2_t out;
+                    if (raw) { out = d2_t{xr, xi}; }
+                    else {
+                        out = d2_t{are * xr - aim * xi, are * xi + aim * xr};
+                        if (has_beta) {
+                            const d2_t old = *(const d2u_t*)c;
+                            out.x += bre * old.x - bim * old.y;
+                            out.y += bre * old.y + bim * old.x;
+                        }
+                    }
+                    *(d2u_t*)c = out;
+                }
+            } else if constexpr (!OPA_C) {
+                #pragma unroll
+                for (int pr = 0; pr < TM / 2; ++pr) {
+                    const int gi = row0 + wrow + 32 * pr + 2 * c16;          // rows gi, gi+1 <- tiles 2pr, 2pr+1
+                    if (gi >= p.m) continue;
+                    double* c = Cb + (long)gj * p.ldc + gi;
+                    double x0 = acc[0][j][2 * pr][g], x1 = acc[0][j][2 * pr + 1][g];
+                    if (!raw) {
+                        x0 *= are; x1 *= are;
+                        if (has_beta) { x0 += bre * c[0]; if (gi + 1 < p.m) x1 += bre * c[1]; }
+                    }
+                    if (gi + 1 < p.m) *(d2u_t*)c = d2_t{x0, x1};
+                    else c[0] = x0;
+                }
+            } else {
+                #pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int gi = row0 + wrow + 16 * i + c16;
+                    if (gi >= p.m) continue;
+                    double* c = Cb + (long)gj * p.ldc + gi;
+                    double x0 = acc[0][j][i][g];
+                    if (!raw) { x0 *= are; if (has_beta) x0 += bre * c[0]; }
+                    c[0] = x0;
+                }
+            }
+        }
+    }
+}
+
+// C = alpha * sum_z slab_z + beta * C    (fixed summation order => bitwise reproducible)
+template <bool CPLX>
+__global__ void splitk_reduce_kernel(const double* __restrict__ slabs, long slab_stride, int splitk, int m, int n,
+                                     double* __restrict__ C, long ldc, double are, double aim, double bre, double bim)
+{
+    const long total = (long)m * n;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(e % m), j = (int)(e / m);
+        if constexpr (CPLX) {
+            double sr = 0.0, si = 0.0;
+            for (int z = 0; z < splitk; ++z) {
+                const d2_t v = *(const d2_t*)(slabs + ((long)z * slab_stride + e) * 2);
+                sr += v.x; si += v.y;
+            }
+            double* c = C + ((long)j * ldc + i) * 2;
+            double orr = are * sr - aim * si, oi = are * si + aim * sr;
+            if (bre != 0.0 || bim != 0.0) { const double cr = c[0], ci = c[1]; orr += bre * cr - bim * ci; oi += bre * ci + bim * cr; }
+            c[0] = orr; c[1] = oi;
+        } else {
+            double s = 0.0;
+            for (int z = 0; z < splitk; ++z) s += slabs[(long)z * slab_stride + e];
+            double* c = C + (long)j * ldc + i;
+            double o = are * s;
+            if (bre != 0.0) o += bre * c[0];
+            c[0] = o;
+        }
+    }
+}
+
+template <bool CPLX, bool OPA_C>
+static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha, const double* A, long lda,
+                       const double* B, long ldb, const double* beta, double* C, long ldc,
+                       double* ws, size_t ws_bytes, int num_cu)
+{
+    using C_ = Cfg<CPLX, OPA_C>;
+    if (m <= 0 || n <= 0) return 0;
+    GemmArgs a;
+    a.A = A; a.B = B; a.C = C; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.m = m; a.n = n; a.k = k;
+    a.gm = (m + C_::BM - 1) / C_::BM; a.gn = (n + C_::BN - 1) / C_::BN;
+    a.alpha_re = alpha[0]; a.alpha_im = CPLX ? alpha[1] : 0.0;
+    a.beta_re = beta[0];   a.beta_im = CPLX ? beta[1] : 0.0;
+    // split-K when the output grid cannot fill the chip (Gram-type products: k = N >> m, n)
+    const long tiles = (long)a.gm * a.gn;
+    const int nkt = (k + C_::BK - 1) / C_::BK;
+    int splitk = 1;
+    const long target = 2L * num_cu;
+    if (tiles < target && nkt >= 16 && ws != nullptr) {
+        splitk = (int)((target + tiles - 1) / tiles);
+        if (splitk > nkt / 8) splitk = nkt / 8;           // keep >= 8 K steps per slice
+        if (splitk > 64) splitk = 64;
+        const size_t slab_bytes = (size_t)m * n * sizeof(double) * C_::EPT;
+        while (splitk > 1 && slab_bytes * splitk > ws_bytes) --splitk;
+        if (splitk < 1) splitk = 1;
+    }
+    int kchunk = ((nkt + splitk - 1) / splitk) * C_::BK;
+    if (kchunk <= 0) kchunk = C_::BK;
+    splitk = (k + kchunk - 1) / kchunk; if (splitk < 1) splitk = 1;
+    a.splitk = splitk; a.kchunk = kchunk;
+    a.slab_stride = 0;
+    if (splitk > 1) { a.C = ws; a.ldc = m; a.slab_stride = (long)m * n; }
+    const unsigned grid = (unsigned)(tiles * splitk);
+    const size_t lds_bytes = 2 * C_::STAGE_UNITS * sizeof(d2_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C>), dim3(grid), dim3(256), lds_bytes, st, a);
+    if (splitk > 1) {
+        const long total = (long)m * n;
+        unsigned rb = (unsigned)((total + 255) / 256); if (rb > 4096) rb = 4096;
+        hipLaunchKernelGGL((splitk_reduce_kernel<CPLX>), dim3(rb), dim3(256), 0, st, ws, (long)m * n, splitk, m, n,
+                           C, ldc, a.alpha_re, a.alpha_im, a.beta_re, a.beta_im);
+    }
+    return (int)hipGetLastError();
+}
+
+int gemm_f64(hipStream_t st, bool cplx, char opA, int m, int n, int k, const double* alpha, const double* A, long lda,
+             const double* B, long ldb, const double* beta, double* C, long ldc, double* ws, size_t ws_bytes, int num_cu)
+{
+    const bool opc = (opA == 'C' || opA == 'c' || opA == 'T' || opA == 't');
+    if (!cplx) {
+        return opc ? launch_gemm<false, true>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu)
+                   : launch_gemm<false, false>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu);
+    }
+    return opc ? launch_gemm<true, true>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu)
+               : launch_gemm<true, false>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu);
+}
+
+// ---- register-resident MFMA peak probe ("to be confirmed by a register-resident MFMA micro-benchmark")
+__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int iters)
+{
+    d4_t acc[8];
+    #pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = d4_t{0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
+    for (int it = 0; it < iters; ++it) {
+        #pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0.0;
+    #pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+int mfma_f64_peak(hipStream_t st, double* out, int blocks, int iters)
+{
+    hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, st, out, iters);
+    return (int)hipGetLastError();
+}
+
+} // namespace chase_hip
