@@ -180,3 +180,173 @@ class Context:
         g = c_double()
         check(lib.chase_hip_hbm_copy_peak(self.h, nbytes, C.byref(g)), "hbm_copy_peak")
         return g.value
+
+
+# ---- non-GEMM kernels -------------------------------------------------------------------------------------------------
+_sig("chase_hip_set_lapack_lib", c_int, C.c_char_p)
+_sig("chase_hip_lapack_provider", C.c_char_p)
+_sig("chase_hip_set_host_threads", c_int, c_int)
+_sig("chase_hip_shift_diag", c_int, c_void_p, c_int, c_int, c_void_p, c_long, c_double)
+_sig("chase_hip_shift_list", c_int, c_void_p, c_int, c_void_p, c_long, c_void_p, c_void_p, c_int, c_double)
+_sig("chase_hip_lacpy", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long)
+_sig("chase_hip_swap_cols", c_int, c_void_p, c_int, c_int, c_void_p, c_long, c_long, c_long)
+_sig("chase_hip_permute_cols", c_int, c_void_p, c_int, c_int, c_void_p, c_long, c_void_p, c_long, P(c_int), P(c_int),
+     c_int)
+_sig("chase_hip_upload_matrix", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long)
+_sig("chase_hip_download_matrix", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long)
+_sig("chase_hip_scale_rows", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_int, c_double)
+_sig("chase_hip_conj", c_int, c_void_p, c_int, c_int, c_void_p, c_long)
+_sig("chase_hip_resid_norms", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p,
+     c_void_p, c_int)
+_sig("chase_hip_herk", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long)
+_sig("chase_hip_abs_trace", c_int, c_void_p, c_int, c_int, c_void_p, c_long, P(c_double))
+_sig("chase_hip_potrf_upper", c_int, c_void_p, c_int, c_int, c_void_p, c_long)
+_sig("chase_hip_trsm_right_upper", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long)
+_sig("chase_hip_cholqr", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_long)
+_sig("chase_hip_houseqr", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long)
+_sig("chase_hip_heevd", c_int, c_void_p, c_int, c_int, c_void_p, c_long, c_void_p)
+_sig("chase_hip_stemr_host", c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int)
+_sig("chase_hip_col_dot", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p)
+_sig("chase_hip_col_nrm2", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p)
+_sig("chase_hip_col_axpy", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_double, c_void_p, c_long,
+     c_void_p, c_long)
+_sig("chase_hip_col_scal", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_long)
+_sig("chase_hip_pack_upper", c_int, c_void_p, c_int, c_int, c_void_p, c_long, c_void_p)
+_sig("chase_hip_unpack_upper", c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_long, c_int)
+
+
+# ---- host solver (include/chase_hip_solver.h) ------------------------------------------------------------------------
+class Stats(C.Structure):
+    _fields_ = [("iterations", c_size_t), ("filtered_vecs", c_size_t), ("lanczos_vecs", c_size_t),
+                ("locked", c_size_t), ("t_all", c_double), ("t_init", c_double), ("t_lanczos", c_double),
+                ("t_filter", c_double), ("t_qr", c_double), ("t_rr", c_double), ("t_resid", c_double),
+                ("filter_ms_device", c_double), ("lowerb", c_double), ("upperb", c_double), ("lambda_", c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_sig("chase_hip_solver_create", c_int, P(c_void_p), c_void_p, c_int, c_size_t, c_size_t, c_size_t, c_void_p, c_size_t,
+     c_void_p, c_size_t, c_void_p, c_int)
+_sig("chase_hip_solver_destroy", c_int, c_void_p)
+_sig("chase_hip_solver_set", c_int, c_void_p, C.c_char_p, c_double)
+_sig("chase_hip_solver_get", c_int, c_void_p, C.c_char_p, P(c_double))
+_sig("chase_hip_solver_solve", c_int, c_void_p, c_int)
+_sig("chase_hip_solver_stats", c_int, c_void_p, P(Stats))
+_sig("chase_hip_solver_resid", P(c_double), c_void_p)
+_sig("chase_hip_solver_trace", C.c_char_p, c_void_p)
+_sig("chase_hip_solver_peek_v", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
+_sig("chase_hip_op_start", c_int, c_void_p)
+_sig("chase_hip_op_end", c_int, c_void_p)
+_sig("chase_hip_op_initvecs", c_int, c_void_p, c_int)
+_sig("chase_hip_op_shift", c_int, c_void_p, c_double, c_int)
+_sig("chase_hip_op_hemm", c_int, c_void_p, c_size_t, P(c_double), P(c_double), c_size_t, c_size_t)
+_sig("chase_hip_op_qr", c_int, c_void_p, c_size_t, c_double)
+_sig("chase_hip_op_rr", c_int, c_void_p, c_void_p, c_size_t)
+_sig("chase_hip_op_resd", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
+_sig("chase_hip_op_swap", c_int, c_void_p, c_size_t, c_size_t)
+_sig("chase_hip_op_lock", c_int, c_void_p, c_size_t)
+_sig("chase_hip_op_lanczos", c_int, c_void_p, c_size_t, c_size_t, P(c_double), c_void_p, c_void_p, c_void_p)
+_sig("chase_hip_op_lanczos_dos", c_int, c_void_p, c_size_t, c_size_t, c_void_p)
+_sig("chase_hip_op_check_symmetry", c_int, c_void_p, P(c_int))
+
+
+class Solver:
+    """ChaseHip<T> behind the C ABI: the reference's ChASEGPU constructor contract (host H, V, ritzv owned by the
+    caller; chase_gpu.hpp:107) plus chase::Solve."""
+
+    def __init__(self, ctx, H, nev, nex, V=None, h_on_device_ptr=None, N=None, cplx=None):
+        self.ctx = ctx
+        if h_on_device_ptr is None:
+            assert H.flags.f_contiguous and H.ndim == 2 and H.shape[0] == H.shape[1]
+            self.cplx = bool(np.iscomplexobj(H))
+            self.N = H.shape[0]
+            self.H = H
+            hptr, on_dev = H.ctypes.data, 0
+        else:
+            self.cplx, self.N, self.H = bool(cplx), int(N), None
+            hptr, on_dev = h_on_device_ptr, 1
+        self.nev, self.nex = nev, nex
+        dt = np.complex128 if self.cplx else np.float64
+        self.V = np.zeros((self.N, nev + nex), dtype=dt, order="F") if V is None else V
+        assert self.V.flags.f_contiguous and self.V.dtype == dt
+        self.ritzv = np.zeros(nev + nex, dtype=np.float64)
+        h = c_void_p()
+        check(lib.chase_hip_solver_create(C.byref(h), ctx.h, int(self.cplx), self.N, nev, nex, hptr, self.N,
+                                          self.V.ctypes.data, self.N, self.ritzv.ctypes.data, on_dev),
+              "solver_create")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.chase_hip_solver_destroy(self.h)
+            self.h = None
+
+    def set(self, **kw):
+        for k, v in kw.items():
+            check(lib.chase_hip_solver_set(self.h, k.encode(), float(v)), f"solver_set({k})")
+
+    def get(self, key):
+        v = c_double()
+        check(lib.chase_hip_solver_get(self.h, key.encode(), C.byref(v)), f"solver_get({key})")
+        return v.value
+
+    def solve(self, trace=False):
+        check(lib.chase_hip_solver_solve(self.h, int(trace)), "solver_solve")
+        return self.stats()
+
+    def stats(self):
+        s = Stats()
+        check(lib.chase_hip_solver_stats(self.h, C.byref(s)), "solver_stats")
+        return s.as_dict()
+
+    def resid(self):
+        p = lib.chase_hip_solver_resid(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.nev + self.nex,)).copy()
+
+    def trace(self):
+        return lib.chase_hip_solver_trace(self.h).decode().splitlines()
+
+    def peek_v(self):
+        out = np.empty_like(self.V, order="F")
+        check(lib.chase_hip_solver_peek_v(self.h, self.ctx.h, out.ctypes.data, self.N), "peek_v")
+        return out
+
+    # ChaseBase virtuals
+    def Start(self): check(lib.chase_hip_op_start(self.h), "Start")
+    def End(self): check(lib.chase_hip_op_end(self.h), "End")
+    def initVecs(self, random): check(lib.chase_hip_op_initvecs(self.h, int(random)), "initVecs")
+    def Shift(self, c, isunshift=False): check(lib.chase_hip_op_shift(self.h, float(c), int(isunshift)), "Shift")
+
+    def HEMM(self, block, alpha, beta, offset_left, offset_right=0):
+        check(lib.chase_hip_op_hemm(self.h, block, _z2(alpha), _z2(beta), offset_left, offset_right), "HEMM")
+
+    def QR(self, fixednev, cond): check(lib.chase_hip_op_qr(self.h, fixednev, float(cond)), "QR")
+
+    def RR(self, block, offset):
+        """ritz values are written to self.ritzv[offset:offset+block] (the driver passes GetRitzv()+locked)."""
+        check(lib.chase_hip_op_rr(self.h, self.ritzv.ctypes.data + 8 * offset, block), "RR")
+
+    def Resd(self, offset):
+        n = self.nev + self.nex - offset
+        out = np.zeros(n)
+        check(lib.chase_hip_op_resd(self.h, self.ritzv.ctypes.data + 8 * offset, out.ctypes.data, offset), "Resd")
+        return out
+
+    def Swap(self, i, j): check(lib.chase_hip_op_swap(self.h, i, j), "Swap")
+    def Lock(self, n): check(lib.chase_hip_op_lock(self.h, n), "Lock")
+
+    def Lanczos(self, M, numvec):
+        ub = c_double()
+        if numvec == 0:
+            check(lib.chase_hip_op_lanczos(self.h, M, 0, C.byref(ub), None, None, None), "Lanczos")
+            return ub.value
+        theta, tau, ritzV = np.zeros(M * numvec), np.zeros(M * numvec), np.zeros(M * M)
+        check(lib.chase_hip_op_lanczos(self.h, M, numvec, C.byref(ub), theta.ctypes.data, tau.ctypes.data,
+                                       ritzV.ctypes.data), "Lanczos")
+        return ub.value, theta, tau, ritzV.reshape(M, M, order="F")
+
+    def checkSymmetryEasy(self):
+        f = c_int()
+        check(lib.chase_hip_op_check_symmetry(self.h, C.byref(f)), "checkSymmetryEasy")
+        return bool(f.value)

@@ -1,0 +1,376 @@
+// capi_blas.hip — C ABI entry points for the non-GEMM kernels of the hot path and the blocked POTRF / TRSM / CholQR
+// drivers built on the MFMA GEMM (include/chase_hip.h).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <vector>
+#include "../../include/chase_hip.h"
+#include "ctx.h"
+#include "kernels.h"
+#include "host_lapack.h"
+
+using namespace chase_hip;
+
+#define HIPCHK(x)                                                                                                      \
+    do {                                                                                                               \
+        hipError_t e_ = (x);                                                                                           \
+        if (e_ != hipSuccess) return hip_fail(e_, #x);                                                                 \
+    } while (0)
+#define KCHK(x, what)                                                                                                  \
+    do {                                                                                                               \
+        int e_ = (x);                                                                                                  \
+        if (e_) return hip_fail((hipError_t)e_, what);                                                                 \
+    } while (0)
+#define RCCHK(x)                                                                                                       \
+    do {                                                                                                               \
+        int r_ = (x);                                                                                                  \
+        if (r_) return r_;                                                                                             \
+    } while (0)
+
+namespace {
+constexpr int NB = 64;
+constexpr size_t WS_DEFAULT = (size_t)64 << 20;
+
+inline int ept_of(int cplx) { return cplx ? 2 : 1; }
+
+// internal GEMM on raw double* with element-unit leading dimensions
+int gemm(chase_hip_ctx* c, int cplx, char op, int m, int n, int k, double ar, double ai, const double* A, long lda,
+         const double* B, long ldb, double br, double bi, double* C, long ldc)
+{
+    if (m <= 0 || n <= 0) return 0;
+    RCCHK(c->ensure_ws(WS_DEFAULT));
+    const double alpha[2] = {ar, ai}, beta[2] = {br, bi};
+    int e = gemm_f64(c->stream, cplx != 0, op, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, (double*)c->ws,
+                     c->ws_bytes, c->num_cu);
+    if (e) return hip_fail((hipError_t)e, "gemm launch");
+    return 0;
+}
+} // namespace
+
+extern "C" {
+
+int chase_hip_set_lapack_lib(const char* path) { return lapack_bind(path); }
+const char* chase_hip_lapack_provider(void)
+{
+    lapack_bind(nullptr);
+    return lapack_provider();
+}
+int chase_hip_set_host_threads(int n)
+{
+    lapack_bind(nullptr);
+    lapack_set_threads(n);
+    return 0;
+}
+
+int chase_hip_shift_diag(chase_hip_ctx* c, int cplx, int n, void* H, long ldh, double shift)
+{
+    if (!c || (!H && n > 0)) return set_error(CHASE_HIP_EINVAL, "shift_diag: NULL argument");
+    if (n < 0 || ldh < n) return set_error(CHASE_HIP_EINVAL, "shift_diag: bad shape");
+    KCHK(shift_diag(c->stream, (double*)H, ldh, n, ept_of(cplx), shift), "shift_diag");
+    return 0;
+}
+
+int chase_hip_shift_list(chase_hip_ctx* c, int cplx, void* H, long ldh, const int* rows_dev, const int* cols_dev, int cnt,
+                         double shift)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "shift_list: NULL ctx");
+    if (cnt < 0) return set_error(CHASE_HIP_EINVAL, "shift_list: negative count");
+    KCHK(shift_list(c->stream, (double*)H, ldh, rows_dev, cols_dev, cnt, ept_of(cplx), shift), "shift_list");
+    return 0;
+}
+
+int chase_hip_lacpy(chase_hip_ctx* c, int cplx, int m, int n, const void* A, long lda, void* B, long ldb)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "lacpy: NULL ctx");
+    if (m < 0 || n < 0 || lda < m || ldb < m) return set_error(CHASE_HIP_EINVAL, "lacpy: bad shape");
+    if (m == 0 || n == 0) return 0;
+    const int e = ept_of(cplx);
+    KCHK(copy2d(c->stream, (const double*)A, lda * e, (double*)B, ldb * e, (long)m * e, n), "lacpy");
+    return 0;
+}
+
+int chase_hip_swap_cols(chase_hip_ctx* c, int cplx, int m, void* V, long ldv, long i, long j)
+{
+    if (!c || !V) return set_error(CHASE_HIP_EINVAL, "swap_cols: NULL argument");
+    if (i == j) return 0;
+    const int e = ept_of(cplx);
+    double* v = (double*)V;
+    KCHK(swap_cols(c->stream, v + i * ldv * e, v + j * ldv * e, (long)m * e), "swap_cols");
+    return 0;
+}
+
+/* V[:, dst[c]] <- V[:, src[c]] for all c simultaneously (scratch: m x (max dst + 1) device matrix, e.g. the second
+ * vector buffer).  src/dst are HOST int arrays.  Applies a batch of deferred column swaps in two launches. */
+int chase_hip_permute_cols(chase_hip_ctx* c, int cplx, int m, void* V, long ldv, void* scratch, long lds_,
+                           const int* src_host, const int* dst_host, int cnt)
+{
+    if (!c || !V || !scratch) return set_error(CHASE_HIP_EINVAL, "permute_cols: NULL argument");
+    if (cnt <= 0) return 0;
+    const int e = ept_of(cplx);
+    RCCHK(c->ensure_buf(chase_hip_ctx::BUF_LAMBDA, (size_t)2 * cnt * sizeof(int) + 64));
+    int* ds = (int*)c->bufs[chase_hip_ctx::BUF_LAMBDA];
+    int* dd = ds + cnt;
+    HIPCHK(hipMemcpyAsync(ds, src_host, (size_t)cnt * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dd, dst_host, (size_t)cnt * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    // the host index arrays may be reused by the caller right after we return
+    HIPCHK(hipStreamSynchronize(c->stream));
+    KCHK(copy_cols_indexed(c->stream, (const double*)V, ldv * e, (double*)scratch, lds_ * e, (long)m * e, ds, dd, cnt),
+         "permute gather");
+    KCHK(copy_cols_indexed(c->stream, (const double*)scratch, lds_ * e, (double*)V, ldv * e, (long)m * e, dd, dd, cnt),
+         "permute scatter");
+    return 0;
+}
+
+/* strided host <-> device matrix transfer (synchronous) */
+int chase_hip_upload_matrix(chase_hip_ctx* c, int cplx, int m, int n, const void* host, long ldh, void* dev, long ldd)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "upload_matrix: NULL ctx");
+    if (m <= 0 || n <= 0) return 0;
+    const size_t es = sizeof(double) * ept_of(cplx);
+    HIPCHK(hipMemcpy2DAsync(dev, (size_t)ldd * es, host, (size_t)ldh * es, (size_t)m * es, n, hipMemcpyHostToDevice,
+                            c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int chase_hip_download_matrix(chase_hip_ctx* c, int cplx, int m, int n, const void* dev, long ldd, void* host, long ldh)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "download_matrix: NULL ctx");
+    if (m <= 0 || n <= 0) return 0;
+    const size_t es = sizeof(double) * ept_of(cplx);
+    HIPCHK(hipMemcpy2DAsync(host, (size_t)ldh * es, dev, (size_t)ldd * es, (size_t)m * es, n, hipMemcpyDeviceToHost,
+                            c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int chase_hip_scale_rows(chase_hip_ctx* c, int cplx, int m, int n, void* X, long ldx, int row0, double s)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "scale_rows: NULL ctx");
+    const int e = ept_of(cplx);
+    KCHK(scale_rows(c->stream, (double*)X, ldx * e, (long)row0 * e, (long)m * e, n, s), "scale_rows");
+    return 0;
+}
+
+int chase_hip_conj(chase_hip_ctx* c, int m, int n, void* X, long ldx)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "conj: NULL ctx");
+    KCHK(conj_inplace(c->stream, (double*)X, ldx * 2, m, n), "conj");
+    return 0;
+}
+
+/* A(n x n) = V^H V, V is k x n.  Full matrix is produced (upper triangle is what CholQR consumes). */
+int chase_hip_herk(chase_hip_ctx* c, int cplx, int n, int k, const void* V, long ldv, void* A, long lda)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "herk: NULL ctx");
+    if (n < 0 || k < 0 || ldv < (k > 1 ? k : 1) || lda < n) return set_error(CHASE_HIP_EINVAL, "herk: bad shape");
+    return gemm(c, cplx, 'C', n, n, k, 1.0, 0.0, (const double*)V, ldv, (const double*)V, ldv, 0.0, 0.0, (double*)A,
+                lda);
+}
+
+int chase_hip_abs_trace(chase_hip_ctx* c, int cplx, int n, const void* A, long lda, double* out_host)
+{
+    if (!c || !out_host) return set_error(CHASE_HIP_EINVAL, "abs_trace: NULL argument");
+    RCCHK(c->ensure_buf(chase_hip_ctx::BUF_SCAL, 4096));
+    double* d = (double*)c->bufs[chase_hip_ctx::BUF_SCAL];
+    KCHK(abs_trace(c->stream, (const double*)A, lda, n, ept_of(cplx), d), "abs_trace");
+    HIPCHK(hipMemcpyAsync(out_host, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+/* In-place upper Cholesky A = R^H R of the device matrix A (n x n); strictly-lower part untouched.
+ * Returns 0 or the LAPACK info (index of the first non-positive pivot, 1-based). */
+int chase_hip_potrf_upper(chase_hip_ctx* c, int cplx, int n, void* A_, long lda)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "potrf: NULL ctx");
+    if (n < 0 || lda < n) return set_error(CHASE_HIP_EINVAL, "potrf: bad shape");
+    if (n == 0) return 0;
+    const int e = ept_of(cplx);
+    double* A = (double*)A_;
+    RCCHK(c->ensure_buf(chase_hip_ctx::BUF_TINV, (size_t)NB * NB * sizeof(double) * e));
+    RCCHK(c->ensure_buf(chase_hip_ctx::BUF_PANEL, (size_t)NB * n * sizeof(double) * e));
+    RCCHK(c->ensure_buf(chase_hip_ctx::BUF_SCAL, 4096));
+    double* Tinv = (double*)c->bufs[chase_hip_ctx::BUF_TINV];
+    double* P = (double*)c->bufs[chase_hip_ctx::BUF_PANEL];
+    int* info_dev = (int*)((char*)c->bufs[chase_hip_ctx::BUF_SCAL] + 2048);
+    HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
+    for (int j0 = 0; j0 < n; j0 += NB) {
+        const int nb = (n - j0 < NB) ? n - j0 : NB;
+        double* Ajj = A + ((long)j0 * lda + j0) * e;
+        KCHK(potf2_trtri(c->stream, cplx != 0, Ajj, lda, nb, j0, Tinv, info_dev), "potf2");
+        const int rest = n - j0 - nb;
+        if (rest > 0) {
+            double* Ajr = A + ((long)(j0 + nb) * lda + j0) * e;            // A[j0 : j0+nb, j0+nb : n]
+            // row panel  R_jr = R_jj^{-H} A_jr
+            RCCHK(gemm(c, cplx, 'C', nb, rest, nb, 1.0, 0.0, Tinv, NB, Ajr, lda, 0.0, 0.0, P, nb));
+            KCHK(copy2d(c->stream, P, (long)nb * e, Ajr, lda * e, (long)nb * e, rest), "potrf panel copy");
+            // trailing update  A_rr -= R_jr^H R_jr
+            double* Arr = A + ((long)(j0 + nb) * lda + (j0 + nb)) * e;
+            RCCHK(gemm(c, cplx, 'C', rest, rest, nb, -1.0, 0.0, Ajr, lda, Ajr, lda, 1.0, 0.0, Arr, lda));
+        }
+    }
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(&info, info_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return info;
+}
+
+/* V (m x n) <- V R^{-1}, R upper triangular n x n (device).  Blocked: diagonal-block inverses + MFMA GEMM sweeps. */
+int chase_hip_trsm_right_upper(chase_hip_ctx* c, int cplx, int m, int n, const void* R_, long ldr, void* V_, long ldv)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "trsm: NULL ctx");
+    if (m < 0 || n < 0 || ldr < n || ldv < m) return set_error(CHASE_HIP_EINVAL, "trsm: bad shape");
+    if (m == 0 || n == 0) return 0;
+    const int e = ept_of(cplx);
+    const double* R = (const double*)R_;
+    double* V = (double*)V_;
+    const int nblk = (n + NB - 1) / NB;
+    RCCHK(c->ensure_buf(chase_hip_ctx::BUF_TINV, (size_t)nblk * NB * NB * sizeof(double) * e));
+    RCCHK(c->ensure_buf(chase_hip_ctx::BUF_PANEL, (size_t)NB * (m > n ? m : n) * sizeof(double) * e));
+    double* Tinv = (double*)c->bufs[chase_hip_ctx::BUF_TINV];
+    double* P = (double*)c->bufs[chase_hip_ctx::BUF_PANEL];
+    KCHK(trtri_diag(c->stream, cplx != 0, R, ldr, n, Tinv), "trtri_diag");
+    for (int b = 0; b < nblk; ++b) {
+        const int j0 = b * NB;
+        const int nb = (n - j0 < NB) ? n - j0 : NB;
+        double* Vj = V + (long)j0 * ldv * e;
+        // X_j = V_j * T_j      (V_j already carries the updates of the previous block columns)
+        RCCHK(gemm(c, cplx, 'N', m, nb, nb, 1.0, 0.0, Vj, ldv, Tinv + (long)b * NB * NB * e, NB, 0.0, 0.0, P, m));
+        KCHK(copy2d(c->stream, P, (long)m * e, Vj, ldv * e, (long)m * e, nb), "trsm panel copy");
+        const int rest = n - j0 - nb;
+        if (rest > 0) {
+            const double* Rjr = R + ((long)(j0 + nb) * ldr + j0) * e;
+            double* Vr = V + (long)(j0 + nb) * ldv * e;
+            RCCHK(gemm(c, cplx, 'N', m, rest, nb, -1.0, 0.0, P, m, Rjr, ldr, 1.0, 0.0, Vr, ldv));
+        }
+    }
+    return 0;
+}
+
+/* Cholesky-QR of V (m x n) in place; A is an n x n device work matrix (lda >= n) that receives the last R.
+ * variant: 1 = CholQR1, 2 = CholQR2, 3 = shifted CholQR2.  m_global is the global row count used in the shift
+ * sqrt(m) * sum|A_ii| * eps (== m on a single GPU).  Returns potrf info like the reference
+ * (linalg/internal/cpu/cholqr1.hpp:41-189): nonzero info of the FIRST factorisation aborts before any trsm. */
+int chase_hip_cholqr(chase_hip_ctx* c, int cplx, int m, int n, void* V, long ldv, void* A, long lda, int variant,
+                     long m_global)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "cholqr: NULL ctx");
+    if (variant < 1 || variant > 3) return set_error(CHASE_HIP_EINVAL, "cholqr: variant must be 1, 2 or 3");
+    if (n == 0 || m == 0) return 0;
+    int info;
+    RCCHK(chase_hip_herk(c, cplx, n, m, V, ldv, A, lda));
+    if (variant == 3) {
+        double nrmf = 0.0;
+        RCCHK(chase_hip_abs_trace(c, cplx, n, A, lda, &nrmf));
+        const double shift = std::sqrt((double)m_global) * nrmf * std::numeric_limits<double>::epsilon();
+        RCCHK(chase_hip_shift_diag(c, cplx, n, A, lda, shift));
+    }
+    info = chase_hip_potrf_upper(c, cplx, n, A, lda);
+    if (info != 0) return info;
+    RCCHK(chase_hip_trsm_right_upper(c, cplx, m, n, A, lda, V, ldv));
+    const int extra = (variant == 1) ? 0 : (variant == 2 ? 1 : 2);
+    for (int r = 0; r < extra; ++r) {
+        RCCHK(chase_hip_herk(c, cplx, n, m, V, ldv, A, lda));
+        info = chase_hip_potrf_upper(c, cplx, n, A, lda);
+        if (info < 0) return info;
+        RCCHK(chase_hip_trsm_right_upper(c, cplx, m, n, A, lda, V, ldv));
+    }
+    return info;
+}
+
+/* resid[j] = || W[:,j] - lambda[j] * V[:,j] ||_2 (or the squared sum when squared != 0), j < n.
+ * lambda_host / resid_host are host arrays of length n. */
+int chase_hip_resid_norms(chase_hip_ctx* c, int cplx, int m, int n, const void* W, long ldw, const void* V, long ldv,
+                          const double* lambda_host, double* resid_host, int squared)
+{
+    if (!c || !resid_host || (V && !lambda_host)) return set_error(CHASE_HIP_EINVAL, "resid_norms: NULL argument");
+    if (n <= 0) return 0;
+    const int e = ept_of(cplx);
+    RCCHK(c->ensure_buf(chase_hip_ctx::BUF_LAMBDA, (size_t)2 * n * sizeof(double)));
+    double* dl = (double*)c->bufs[chase_hip_ctx::BUF_LAMBDA];
+    double* dr = dl + n;
+    if (V) HIPCHK(hipMemcpyAsync(dl, lambda_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    KCHK(resid_norms(c->stream, (const double*)W, ldw * e, (const double*)V, ldv * e, dl, (long)m * e, n, dr,
+                     squared ? 0 : 1), "resid_norms");
+    HIPCHK(hipMemcpyAsync(resid_host, dr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+/* Hermitian eigendecomposition of the device matrix A (n x n, lower triangle referenced) on the HOST
+ * (north star: "small HEEV on host"; reference lapackpp::t_heevd 'V','L').  Eigenvalues ascending to w_host,
+ * eigenvectors overwrite A on the device. */
+int chase_hip_heevd(chase_hip_ctx* c, int cplx, int n, void* A, long lda, double* w_host)
+{
+    if (!c || !w_host) return set_error(CHASE_HIP_EINVAL, "heevd: NULL argument");
+    if (n < 0 || lda < n) return set_error(CHASE_HIP_EINVAL, "heevd: bad shape");
+    if (n == 0) return 0;
+    const int e = ept_of(cplx);
+    const size_t colb = (size_t)n * sizeof(double) * e;
+    RCCHK(c->ensure_hstage(colb * n));
+    double* h = (double*)c->hstage;
+    HIPCHK(hipMemcpy2DAsync(h, colb, A, (size_t)lda * sizeof(double) * e, colb, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    RCCHK(host_heevd(cplx != 0, n, h, n, w_host));
+    HIPCHK(hipMemcpy2DAsync(A, (size_t)lda * sizeof(double) * e, h, colb, colb, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+/* host-only helper: all eigenpairs of a symmetric tridiagonal matrix (reference lapackpp::t_stemr, cpu/lanczos.hpp:188) */
+int chase_hip_stemr_host(int n, double* d, double* e, double* w, double* Z, int ldz)
+{
+    return host_stemr(n, d, e, w, Z, ldz);
+}
+
+/* ---- batched column (multi-vector) level-1 kernels with device-resident scalars ------------------------------ */
+int chase_hip_col_dot(chase_hip_ctx* c, int cplx, int m, int n, const void* X, long ldx, const void* Y, long ldy,
+                      double* out_dev)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "col_dot: NULL ctx");
+    const int e = ept_of(cplx);
+    KCHK(col_dot(c->stream, cplx != 0, (const double*)X, ldx * e, (const double*)Y, ldy * e, m, n, out_dev), "col_dot");
+    return 0;
+}
+int chase_hip_col_nrm2(chase_hip_ctx* c, int cplx, int m, int n, const void* X, long ldx, double* out_dev)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "col_nrm2: NULL ctx");
+    const int e = ept_of(cplx);
+    KCHK(resid_norms(c->stream, (const double*)X, ldx * e, nullptr, 0, nullptr, (long)m * e, n, out_dev, 1), "col_nrm2");
+    return 0;
+}
+int chase_hip_col_axpy(chase_hip_ctx* c, int cplx, int m, int n, const double* a_dev, int a_is_real, int a_stride,
+                       double sgn, const void* X, long ldx, void* Y, long ldy)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "col_axpy: NULL ctx");
+    const int e = ept_of(cplx);
+    KCHK(col_axpy(c->stream, cplx != 0, a_dev, a_is_real, a_stride, sgn, (const double*)X, ldx * e, (double*)Y, ldy * e,
+                  m, n), "col_axpy");
+    return 0;
+}
+int chase_hip_col_scal(chase_hip_ctx* c, int cplx, int m, int n, const double* a_dev, int inverse, void* X, long ldx)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "col_scal: NULL ctx");
+    const int e = ept_of(cplx);
+    KCHK(col_scal(c->stream, a_dev, inverse, (double*)X, ldx * e, (long)m * e, n), "col_scal");
+    return 0;
+}
+
+/* pack / unpack the upper triangle (column-packed) — halves the Gram all-reduce payload */
+int chase_hip_pack_upper(chase_hip_ctx* c, int cplx, int n, const void* A, long lda, void* P)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "pack_upper: NULL ctx");
+    KCHK(pack_upper(c->stream, (const double*)A, lda, n, ept_of(cplx), (double*)P), "pack_upper");
+    return 0;
+}
+int chase_hip_unpack_upper(chase_hip_ctx* c, int cplx, int n, const void* P, void* A, long lda, int mirror)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "unpack_upper: NULL ctx");
+    KCHK(unpack_upper(c->stream, (double*)P, n, ept_of(cplx), (double*)A, lda), "unpack_upper");
+    if (mirror) KCHK(mirror_upper(c->stream, (double*)A, lda, n, ept_of(cplx)), "mirror_upper");
+    return 0;
+}
+
+} // extern "C"

@@ -77,6 +77,9 @@ int chase_hip_ctx_destroy(chase_hip_ctx* c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     if (c->ws) hipFree(c->ws);
+    for (int i = 0; i < chase_hip_ctx::NBUF; ++i)
+        if (c->bufs[i]) hipFree(c->bufs[i]);
+    if (c->hstage) hipHostFree(c->hstage);
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);
     if (c->own_stream) hipStreamDestroy(c->stream);

@@ -12,10 +12,17 @@ struct chase_hip_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    void* ws = nullptr;          // split-K slabs / scratch, grown on demand
+    void* ws = nullptr;          // split-K slabs, grown on demand
     size_t ws_bytes = 0;
+    enum { BUF_TINV = 0, BUF_PANEL, BUF_SCAL, BUF_LAMBDA, NBUF };
+    void* bufs[NBUF] = {nullptr, nullptr, nullptr, nullptr};   // device scratch, grown on demand
+    size_t buf_bytes[NBUF] = {0, 0, 0, 0};
+    void* hstage = nullptr;      // pinned host staging (HEEVD round trip)
+    size_t hstage_bytes = 0;
 
     int ensure_ws(size_t bytes);
+    int ensure_buf(int idx, size_t bytes);
+    int ensure_hstage(size_t bytes);
 };
 
 namespace chase_hip {

@@ -1,0 +1,278 @@
+// hhqr.hip — Householder QR fallback on the device: V (m x n) <- first n columns of Q with V = Q R.
+//
+// Reference behaviour replaced: cpu::houseHoulderQR = geqrf + ungqr (linalg/internal/cpu/cholqr1.hpp:203-210;
+// cusolverDnTgeqrf / Tgqr in linalg/internal/cuda/cholqr.hpp:549-556), taken when potrf fails or CholQR is disabled
+// (Impl/chase_cpu/chase_cpu.hpp:650-776).  Structure: blocked compact-WY (panel width 32, like the reference's
+// distributed variant, linalg/internal/mpi/householder_qr.hpp:772-1054):
+//   panel:    per column one reflector-generation launch (wave-shuffle norm) + one launch applying it to the
+//             remaining panel columns (one workgroup per column: dot, then update)
+//   T factor: G = V^H V with the split-K MFMA GEMM, forward recurrence in one workgroup
+//   trailing: C -= V T^H (V^H C)  — three MFMA GEMMs;   form Q: backward accumulation with the same GEMMs.
+// All scalars (tau, beta) stay on the device: no host synchronisation inside the factorisation.
+
+#include <hip/hip_runtime.h>
+#include "../../include/chase_hip.h"
+#include "ctx.h"
+#include "kernels.h"
+
+namespace chase_hip {
+
+constexpr int HNB = 32;
+
+__device__ __forceinline__ double wsum(double v)
+{
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double bsum256(double v, double* sm)   // result broadcast to all threads
+{
+    v = wsum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// LAPACK xLARFG on column j of A (rows j..m-1): A[j,j] <- beta, A[j+1:,j] <- v (v_j = 1 implicit), tau[j].
+template <bool CPLX>
+__global__ __launch_bounds__(256) void house_gen_kernel(double* __restrict__ A, long lda, int m, int j,
+                                                        double* __restrict__ tau)
+{
+    __shared__ double sm[4];
+    constexpr int E = CPLX ? 2 : 1;
+    double* col = A + ((long)j * lda) * E;
+    double s = 0.0;
+    for (long i = (long)(j + 1) * E + threadIdx.x; i < (long)m * E; i += 256) { const double x = col[i]; s += x * x; }
+    const double xn2 = bsum256(s, sm);
+    const double ar = col[(long)j * E], ai = CPLX ? col[(long)j * E + 1] : 0.0;
+    if (xn2 == 0.0 && ai == 0.0) {                    // H = I
+        if (threadIdx.x == 0) { tau[j * E] = 0.0; if (CPLX) tau[j * E + 1] = 0.0; }
+        return;
+    }
+    const double nrm = sqrt(ar * ar + ai * ai + xn2);
+    const double beta = (ar >= 0.0) ? -nrm : nrm;
+    // scale = 1 / (alpha - beta)
+    const double dr = ar - beta, di = ai;
+    const double den = dr * dr + di * di;
+    const double sr = dr / den, si = -di / den;
+    __syncthreads();
+    for (long i = (long)(j + 1) + threadIdx.x; i < m; i += 256) {
+        if constexpr (CPLX) {
+            const double xr = col[2 * i], xi = col[2 * i + 1];
+            col[2 * i] = xr * sr - xi * si;
+            col[2 * i + 1] = xr * si + xi * sr;
+        } else {
+            col[i] *= sr;
+        }
+    }
+    if (threadIdx.x == 0) {
+        tau[j * E] = (beta - ar) / beta;
+        if (CPLX) tau[j * E + 1] = -ai / beta;
+        col[(long)j * E] = beta;
+        if (CPLX) col[(long)j * E + 1] = 0.0;
+    }
+}
+
+// apply H_j^H = I - conj(tau) v v^H to columns c0 .. c0+ncols-1 (one workgroup per column)
+template <bool CPLX>
+__global__ __launch_bounds__(256) void house_apply_kernel(double* __restrict__ A, long lda, int m, int j, int c0,
+                                                          const double* __restrict__ tau)
+{
+    __shared__ double sm[4];
+    constexpr int E = CPLX ? 2 : 1;
+    const int c = c0 + blockIdx.x;
+    const double* v = A + ((long)j * lda) * E;
+    double* a = A + ((long)c * lda) * E;
+    const double tr = tau[j * E], ti = CPLX ? tau[j * E + 1] : 0.0;
+    if (tr == 0.0 && ti == 0.0) return;
+    double wr = 0.0, wi = 0.0;                         // w = v^H a
+    for (long i = (long)(j + 1) + threadIdx.x; i < m; i += 256) {
+        if constexpr (CPLX) {
+            const double vr = v[2 * i], vi = v[2 * i + 1], xr = a[2 * i], xi = a[2 * i + 1];
+            wr += vr * xr + vi * xi;
+            wi += vr * xi - vi * xr;
+        } else {
+            wr += v[i] * a[i];
+        }
+    }
+    wr = bsum256(wr, sm);
+    if (CPLX) wi = bsum256(wi, sm);
+    wr += a[(long)j * E];
+    if (CPLX) wi += a[(long)j * E + 1];
+    // f = conj(tau) * w
+    const double fr = tr * wr + ti * wi, fi = tr * wi - ti * wr;
+    __syncthreads();
+    for (long i = (long)(j + 1) + threadIdx.x; i < m; i += 256) {
+        if constexpr (CPLX) {
+            const double vr = v[2 * i], vi = v[2 * i + 1];
+            a[2 * i] -= fr * vr - fi * vi;
+            a[2 * i + 1] -= fr * vi + fi * vr;
+        } else {
+            a[i] -= fr * v[i];
+        }
+    }
+    if (threadIdx.x == 0) {
+        a[(long)j * E] -= fr;
+        if (CPLX) a[(long)j * E + 1] -= fi;
+    }
+}
+
+// Vb (rows x nb, ld = rows) <- unit lower trapezoid of A[j0:m, j0:j0+nb]
+__global__ __launch_bounds__(256) void extract_v_kernel(const double* __restrict__ A, long lda, int m, int j0, int nb,
+                                                        int ept, double* __restrict__ Vb)
+{
+    const int rows = m - j0;
+    const int c = blockIdx.y;
+    if (c >= nb) return;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
+        for (int e = 0; e < ept; ++e) {
+            double v;
+            if (r < c) v = 0.0;
+            else if (r == c) v = (e == 0) ? 1.0 : 0.0;
+            else v = A[((long)(j0 + c) * lda + j0 + r) * ept + e];
+            Vb[((long)c * rows + r) * ept + e] = v;
+        }
+    }
+}
+
+// LAPACK xLARFT (forward, columnwise) from G = V^H V:  T[i,i] = tau_i;  T[0:i,i] = -tau_i * T[0:i,0:i] * G[0:i,i]
+template <bool CPLX>
+__global__ __launch_bounds__(64) void larft_kernel(const double* __restrict__ G, int nb, const double* __restrict__ tau,
+                                                   double* __restrict__ T)
+{
+    constexpr int E = CPLX ? 2 : 1;
+    __shared__ double t[HNB * HNB * 2];
+    __shared__ double g[HNB * 2];
+    const int r = threadIdx.x;
+    for (int e = r; e < HNB * HNB * E; e += 64) t[e] = 0.0;
+    __syncthreads();
+    for (int i = 0; i < nb; ++i) {
+        const double tr = tau[i * E], ti = CPLX ? tau[i * E + 1] : 0.0;
+        if (r < i) { g[r * E] = G[((long)i * nb + r) * E]; if (CPLX) g[r * E + 1] = G[((long)i * nb + r) * E + 1]; }
+        __syncthreads();
+        if (r < i) {                                   // row r of upper-triangular T[0:i,0:i] times g
+            double sr = 0.0, si = 0.0;
+            for (int l = r; l < i; ++l) {
+                const double ar = t[(l * HNB + r) * E], ai = CPLX ? t[(l * HNB + r) * E + 1] : 0.0;
+                const double br = g[l * E], bi = CPLX ? g[l * E + 1] : 0.0;
+                sr += ar * br - ai * bi;
+                si += ar * bi + ai * br;
+            }
+            t[(i * HNB + r) * E] = -(tr * sr - ti * si);
+            if (CPLX) t[(i * HNB + r) * E + 1] = -(tr * si + ti * sr);
+        }
+        if (r == i) { t[(i * HNB + i) * E] = tr; if (CPLX) t[(i * HNB + i) * E + 1] = ti; }
+        __syncthreads();
+    }
+    for (int e = r; e < HNB * HNB * E; e += 64) T[e] = t[e];
+}
+
+// Q (m x n, ld = m) <- first n columns of the identity
+__global__ __launch_bounds__(256) void set_identity_kernel(double* __restrict__ Q, int m, int n, int ept)
+{
+    const int c = blockIdx.y;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < m; r += gridDim.x * 256)
+        for (int e = 0; e < ept; ++e) Q[((long)c * m + r) * ept + e] = (r == c && e == 0) ? 1.0 : 0.0;
+}
+
+} // namespace chase_hip
+
+using namespace chase_hip;
+
+#define KL(x)                                                                                                          \
+    do {                                                                                                               \
+        x;                                                                                                             \
+        hipError_t e_ = hipGetLastError();                                                                             \
+        if (e_ != hipSuccess) return hip_fail(e_, #x);                                                                 \
+    } while (0)
+#define RC(x)                                                                                                          \
+    do {                                                                                                               \
+        int r_ = (x);                                                                                                  \
+        if (r_) return r_;                                                                                             \
+    } while (0)
+
+static int g3(chase_hip_ctx* c, bool cplx, char op, int m, int n, int k, double ar, const double* A, long lda,
+              const double* B, long ldb, double br, double* C, long ldc)
+{
+    if (m <= 0 || n <= 0) return 0;
+    const double alpha[2] = {ar, 0.0}, beta[2] = {br, 0.0};
+    int e = gemm_f64(c->stream, cplx, op, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, (double*)c->ws, c->ws_bytes,
+                     c->num_cu);
+    if (e) return hip_fail((hipError_t)e, "gemm launch");
+    return 0;
+}
+
+extern "C" int chase_hip_houseqr(chase_hip_ctx* c, int cplx_, int m, int n, void* V_, long ldv)
+{
+    if (!c || !V_) return set_error(CHASE_HIP_EINVAL, "houseqr: NULL argument");
+    if (m < n || n < 0 || ldv < m) return set_error(CHASE_HIP_EINVAL, "houseqr: need m >= n and ldv >= m");
+    if (n == 0) return 0;
+    const bool cplx = cplx_ != 0;
+    const int E = cplx ? 2 : 1;
+    double* A = (double*)V_;
+    hipStream_t st = c->stream;
+    const int npan = (n + HNB - 1) / HNB;
+    RC(c->ensure_ws((size_t)64 << 20));
+    // one scratch block: Q (m x n) | Vb (m x nb) | W1, W2 (nb x n) | G (nb x nb) | T (npan x nb x nb) | tau (n)
+    const size_t szQ = (size_t)m * n * E, szV = (size_t)m * HNB * E, szW = (size_t)HNB * n * E;
+    const size_t szG = (size_t)HNB * HNB * E, szT = (size_t)npan * HNB * HNB * E, szTau = (size_t)n * E;
+    double* blk = nullptr;
+    hipError_t he = hipMalloc((void**)&blk, (szQ + szV + 2 * szW + szG + szT + szTau) * sizeof(double));
+    if (he != hipSuccess) return set_error(CHASE_HIP_ENOMEM, "houseqr: scratch allocation failed");
+    double* Q = blk; double* Vb = Q + szQ; double* W1 = Vb + szV; double* W2 = W1 + szW; double* G = W2 + szW;
+    double* T = G + szG; double* tau = T + szT;
+    int rc = 0;
+    auto body = [&]() -> int {
+        for (int p = 0; p < npan; ++p) {
+            const int j0 = p * HNB, nb = (n - j0 < HNB) ? n - j0 : HNB, pend = j0 + nb;
+            for (int j = j0; j < pend; ++j) {
+                if (cplx) KL(hipLaunchKernelGGL(house_gen_kernel<true>, dim3(1), dim3(256), 0, st, A, ldv, m, j, tau));
+                else      KL(hipLaunchKernelGGL(house_gen_kernel<false>, dim3(1), dim3(256), 0, st, A, ldv, m, j, tau));
+                const int nc = pend - j - 1;
+                if (nc > 0) {
+                    if (cplx) KL(hipLaunchKernelGGL(house_apply_kernel<true>, dim3(nc), dim3(256), 0, st, A, ldv, m, j, j + 1, tau));
+                    else      KL(hipLaunchKernelGGL(house_apply_kernel<false>, dim3(nc), dim3(256), 0, st, A, ldv, m, j, j + 1, tau));
+                }
+            }
+            const int rows = m - j0;
+            unsigned gx = (unsigned)((rows + 1023) / 1024); if (gx > 64) gx = 64; if (gx < 1) gx = 1;
+            KL(hipLaunchKernelGGL(extract_v_kernel, dim3(gx, nb), dim3(256), 0, st, A, ldv, m, j0, nb, E, Vb));
+            RC(g3(c, cplx, 'C', nb, nb, rows, 1.0, Vb, rows, Vb, rows, 0.0, G, nb));
+            double* Tp = T + (size_t)p * HNB * HNB * E;
+            if (cplx) KL(hipLaunchKernelGGL(larft_kernel<true>, dim3(1), dim3(64), 0, st, G, nb, tau + (size_t)j0 * E, Tp));
+            else      KL(hipLaunchKernelGGL(larft_kernel<false>, dim3(1), dim3(64), 0, st, G, nb, tau + (size_t)j0 * E, Tp));
+            const int nt = n - pend;
+            if (nt > 0) {                               // C -= V T^H (V^H C)
+                double* Cm = A + ((long)pend * ldv + j0) * E;
+                RC(g3(c, cplx, 'C', nb, nt, rows, 1.0, Vb, rows, Cm, ldv, 0.0, W1, nb));
+                RC(g3(c, cplx, 'C', nb, nt, nb, 1.0, Tp, HNB, W1, nb, 0.0, W2, nb));
+                RC(g3(c, cplx, 'N', rows, nt, nb, -1.0, Vb, rows, W2, nb, 1.0, Cm, ldv));
+            }
+        }
+        // ---- form Q = H_1 ... H_k I(:, 1:n) by backward accumulation ----
+        {
+            unsigned gx = (unsigned)((m + 1023) / 1024); if (gx > 64) gx = 64; if (gx < 1) gx = 1;
+            KL(hipLaunchKernelGGL(set_identity_kernel, dim3(gx, n), dim3(256), 0, st, Q, m, n, E));
+        }
+        for (int p = npan - 1; p >= 0; --p) {
+            const int j0 = p * HNB, nb = (n - j0 < HNB) ? n - j0 : HNB;
+            const int rows = m - j0, nq = n - j0;
+            unsigned gx = (unsigned)((rows + 1023) / 1024); if (gx > 64) gx = 64; if (gx < 1) gx = 1;
+            KL(hipLaunchKernelGGL(extract_v_kernel, dim3(gx, nb), dim3(256), 0, st, A, ldv, m, j0, nb, E, Vb));
+            double* Tp = T + (size_t)p * HNB * HNB * E;
+            double* Qs = Q + ((long)j0 * m + j0) * E;                    // Q[j0:m, j0:n]
+            RC(g3(c, cplx, 'C', nb, nq, rows, 1.0, Vb, rows, Qs, m, 0.0, W1, nb));
+            RC(g3(c, cplx, 'N', nb, nq, nb, 1.0, Tp, HNB, W1, nb, 0.0, W2, nb));
+            RC(g3(c, cplx, 'N', rows, nq, nb, -1.0, Vb, rows, W2, nb, 1.0, Qs, m));
+        }
+        int e = copy2d(st, Q, (long)m * E, A, ldv * E, (long)m * E, n);
+        if (e) return hip_fail((hipError_t)e, "houseqr copy-back");
+        return 0;
+    };
+    rc = body();
+    hipStreamSynchronize(st);
+    hipFree(blk);
+    return rc;
+}

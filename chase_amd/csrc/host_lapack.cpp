@@ -1,0 +1,163 @@
+// host_lapack.cpp — dlopen-bound LAPACK (LP64, Fortran calling convention).
+// Providers tried in order: $CHASE_HIP_LAPACK_LIB, an explicit hint, scipy's bundled OpenBLAS (LP64, "scipy_" prefix),
+// MKL's single dynamic library.  No provider => CHASE_HIP_ELAPACK (the product never falls back silently).
+#include <dlfcn.h>
+#include <glob.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <mutex>
+#include "host_lapack.h"
+#include "ctx.h"
+#include "../../include/chase_hip.h"
+
+namespace chase_hip {
+
+typedef void (*dsyevd_t)(const char*, const char*, const int*, double*, const int*, double*, double*, const int*, int*,
+                         const int*, int*);
+typedef void (*zheevd_t)(const char*, const char*, const int*, void*, const int*, double*, void*, const int*, double*,
+                         const int*, int*, const int*, int*);
+typedef void (*dstemr_t)(const char*, const char*, const int*, double*, double*, const double*, const double*,
+                         const int*, const int*, int*, double*, double*, const int*, const int*, int*, int*, double*,
+                         const int*, int*, const int*, int*);
+typedef void (*set_threads_t)(int);
+
+static void* g_handle = nullptr;
+static dsyevd_t g_dsyevd = nullptr;
+static zheevd_t g_zheevd = nullptr;
+static dstemr_t g_dstemr = nullptr;
+static set_threads_t g_set_threads = nullptr;
+static std::string g_provider;
+static std::mutex g_mu;
+
+static void* sym_any(void* h, const char* base)
+{
+    const std::string b(base);
+    const std::string cands[] = {"scipy_" + b + "_", b + "_", b, "scipy_" + b};
+    for (const auto& c : cands) {
+        void* p = dlsym(h, c.c_str());
+        if (p) return p;
+    }
+    return nullptr;
+}
+
+static bool try_lib(const char* path)
+{
+    if (!path || !*path) return false;
+    void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return false;
+    dsyevd_t a = (dsyevd_t)sym_any(h, "dsyevd");
+    zheevd_t b = (zheevd_t)sym_any(h, "zheevd");
+    dstemr_t c = (dstemr_t)sym_any(h, "dstemr");
+    if (!a || !b || !c) { dlclose(h); return false; }
+    g_handle = h; g_dsyevd = a; g_zheevd = b; g_dstemr = c;
+    g_set_threads = (set_threads_t)dlsym(h, "scipy_openblas_set_num_threads");
+    if (!g_set_threads) g_set_threads = (set_threads_t)dlsym(h, "openblas_set_num_threads");
+    if (!g_set_threads) g_set_threads = (set_threads_t)dlsym(h, "MKL_Set_Num_Threads");
+    g_provider = path;
+    return true;
+}
+
+static bool try_glob(const char* pattern)
+{
+    glob_t g;
+    bool ok = false;
+    if (glob(pattern, 0, nullptr, &g) == 0) {
+        for (size_t i = 0; i < g.gl_pathc && !ok; ++i) ok = try_lib(g.gl_pathv[i]);
+    }
+    globfree(&g);
+    return ok;
+}
+
+int lapack_bind(const char* hint)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_handle) return 0;
+    if (try_lib(getenv("CHASE_HIP_LAPACK_LIB"))) return 0;
+    if (try_lib(hint)) return 0;
+    const char* pats[] = {
+        "/usr/local/lib/python3*/dist-packages/scipy.libs/libscipy_openblas-*.so",
+        "/usr/lib/python3*/dist-packages/scipy.libs/libscipy_openblas-*.so",
+        "/opt/conda/lib/python3*/site-packages/scipy.libs/libscipy_openblas-*.so",
+        "/usr/lib/x86_64-linux-gnu/liblapack.so.3",
+        "/usr/lib/x86_64-linux-gnu/libopenblas.so.0",
+    };
+    for (const char* p : pats)
+        if (try_glob(p)) return 0;
+    // MKL single dynamic library: LP64 + GNU threading so that it coexists with libgomp users in the process
+    setenv("MKL_INTERFACE_LAYER", "LP64", 0);
+    setenv("MKL_THREADING_LAYER", "GNU", 0);
+    if (try_lib("/opt/conda/lib/libmkl_rt.so") || try_lib("libmkl_rt.so")) return 0;
+    return set_error(CHASE_HIP_ELAPACK,
+                     "no host LAPACK provider found (set CHASE_HIP_LAPACK_LIB to an LP64 LAPACK shared library)");
+}
+
+const char* lapack_provider() { return g_provider.c_str(); }
+
+void lapack_set_threads(int n)
+{
+    if (g_set_threads && n > 0) g_set_threads(n);
+}
+
+int host_heevd(bool cplx, int n, double* A, int lda, double* w)
+{
+    if (n <= 0) return 0;
+    int rc = lapack_bind(nullptr);
+    if (rc) return rc;
+    int info = 0, lwork = -1, lrwork = -1, liwork = -1;
+    const char jobz = 'V', uplo = 'L';
+    if (!cplx) {
+        double wq; int iwq;
+        g_dsyevd(&jobz, &uplo, &n, A, &lda, w, &wq, &lwork, &iwq, &liwork, &info);
+        if (info) return set_error(CHASE_HIP_ENOTCONV, "dsyevd workspace query failed");
+        lwork = (int)wq; liwork = iwq;
+        std::vector<double> work((size_t)lwork);
+        std::vector<int> iwork((size_t)liwork);
+        g_dsyevd(&jobz, &uplo, &n, A, &lda, w, work.data(), &lwork, iwork.data(), &liwork, &info);
+    } else {
+        double wq[2], rwq; int iwq;
+        g_zheevd(&jobz, &uplo, &n, A, &lda, w, wq, &lwork, &rwq, &lrwork, &iwq, &liwork, &info);
+        if (info) return set_error(CHASE_HIP_ENOTCONV, "zheevd workspace query failed");
+        lwork = (int)wq[0]; lrwork = (int)rwq; liwork = iwq;
+        std::vector<double> work(2 * (size_t)lwork), rwork((size_t)lrwork);
+        std::vector<int> iwork((size_t)liwork);
+        g_zheevd(&jobz, &uplo, &n, A, &lda, w, work.data(), &lwork, rwork.data(), &lrwork, iwork.data(), &liwork, &info);
+    }
+    if (info != 0) {
+        char buf[128];
+        snprintf(buf, sizeof buf, "host heevd failed, info = %d", info);
+        return set_error(info > 0 ? CHASE_HIP_ENOTCONV : CHASE_HIP_EINVAL, buf);
+    }
+    return 0;
+}
+
+int host_stemr(int n, double* d, double* e, double* w, double* Z, int ldz)
+{
+    if (n <= 0) return 0;
+    int rc = lapack_bind(nullptr);
+    if (rc) return rc;
+    const char jobz = 'V', range = 'A';
+    const double vl = 0, vu = 0;
+    const int il = 0, iu = 0;
+    int m = 0, nzc = n, tryrac = 0, info = 0, lwork = -1, liwork = -1;
+    std::vector<int> isuppz(2 * (size_t)n);
+    double wq; int iwq;
+    g_dstemr(&jobz, &range, &n, d, e, &vl, &vu, &il, &iu, &m, w, Z, &ldz, &nzc, isuppz.data(), &tryrac, &wq, &lwork,
+             &iwq, &liwork, &info);
+    if (info) return set_error(CHASE_HIP_ENOTCONV, "dstemr workspace query failed");
+    lwork = (int)wq; liwork = iwq;
+    std::vector<double> work((size_t)lwork);
+    std::vector<int> iwork((size_t)liwork);
+    g_dstemr(&jobz, &range, &n, d, e, &vl, &vu, &il, &iu, &m, w, Z, &ldz, &nzc, isuppz.data(), &tryrac, work.data(),
+             &lwork, iwork.data(), &liwork, &info);
+    if (info != 0 || m != n) {
+        char buf[128];
+        snprintf(buf, sizeof buf, "host stemr failed, info = %d, m = %d of %d", info, m, n);
+        return set_error(CHASE_HIP_ENOTCONV, buf);
+    }
+    return 0;
+}
+
+} // namespace chase_hip

@@ -15,4 +15,31 @@ int gemm_f64(hipStream_t st, bool cplx, char opA, int m, int n, int k, const dou
 int mfma_f64_peak(hipStream_t st, double* out, int blocks, int iters);
 int stream_copy(hipStream_t st, void* dst, const void* src, size_t bytes);
 
+// ---- streaming / reduction kernels (vec_kernels.hip); *_d arguments are in doubles (m*ept, ld*ept) ----
+int shift_diag(hipStream_t st, double* H, long ld, int n, int ept, double shift);
+int shift_list(hipStream_t st, double* H, long ld, const int* rows, const int* cols, int cnt, int ept, double shift);
+int shift_diag_dev(hipStream_t st, double* A, long ld, int n, int ept, const double* nrmf_dev, double factor);
+int abs_trace(hipStream_t st, const double* A, long ld, int n, int ept, double* out_dev);
+int copy2d(hipStream_t st, const double* src, long ld_src_d, double* dst, long ld_dst_d, long md, int ncols);
+int swap_cols(hipStream_t st, double* a, double* b, long md);
+int copy_cols_indexed(hipStream_t st, const double* src, long ld_src_d, double* dst, long ld_dst_d, long md,
+                      const int* src_idx_dev, const int* dst_idx_dev, int cnt);
+int resid_norms(hipStream_t st, const double* W, long ldw_d, const double* V, long ldv_d, const double* lambda_dev,
+                long md, int ncols, double* out_dev, int do_sqrt);
+int sqrt_inplace(hipStream_t st, double* x, int n);
+int col_dot(hipStream_t st, bool cplx, const double* X, long ldx_d, const double* Y, long ldy_d, int m, int ncols,
+            double* out_dev);
+int col_axpy(hipStream_t st, bool cplx, const double* a_dev, int a_is_real, int a_stride, double sgn, const double* X,
+             long ldx_d, double* Y, long ldy_d, int m, int ncols);
+int col_scal(hipStream_t st, const double* a_dev, int inv, double* X, long ldx_d, long md, int ncols);
+int scale_rows(hipStream_t st, double* X, long ldx_d, long row0_d, long md, int ncols, double s);
+int conj_inplace(hipStream_t st, double* X, long ldx_d, int m, int ncols);
+int pack_upper(hipStream_t st, const double* A, long lda, int n, int ept, double* P);
+int unpack_upper(hipStream_t st, double* P, int n, int ept, double* A, long lda);
+int mirror_upper(hipStream_t st, double* A, long lda, int n, int ept);
+
+// ---- factorisation cores (factor_kernels.hip) ----
+int potf2_trtri(hipStream_t st, bool cplx, double* A, long lda, int nb, int joff, double* Tinv, int* info_dev);
+int trtri_diag(hipStream_t st, bool cplx, const double* R, long ldr, int n, double* Tinv);
+
 } // namespace chase_hip

@@ -14,6 +14,26 @@ int chase_hip_ctx::ensure_ws(size_t bytes)
     return 0;
 }
 
+int chase_hip_ctx::ensure_buf(int idx, size_t bytes)
+{
+    if (buf_bytes[idx] >= bytes) return 0;
+    if (bufs[idx]) { hipStreamSynchronize(stream); hipFree(bufs[idx]); bufs[idx] = nullptr; buf_bytes[idx] = 0; }
+    hipError_t e = hipMalloc(&bufs[idx], bytes);
+    if (e != hipSuccess) return chase_hip::set_error(CHASE_HIP_ENOMEM, "scratch allocation failed");
+    buf_bytes[idx] = bytes;
+    return 0;
+}
+
+int chase_hip_ctx::ensure_hstage(size_t bytes)
+{
+    if (hstage_bytes >= bytes) return 0;
+    if (hstage) { hipStreamSynchronize(stream); hipHostFree(hstage); hstage = nullptr; hstage_bytes = 0; }
+    hipError_t e = hipHostMalloc(&hstage, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return chase_hip::set_error(CHASE_HIP_ENOMEM, "pinned staging allocation failed");
+    hstage_bytes = bytes;
+    return 0;
+}
+
 namespace chase_hip {
 
 __global__ __launch_bounds__(256) void stream_copy_kernel(float4* __restrict__ dst, const float4* __restrict__ src, size_t n16)
@@ -26,6 +46,376 @@ int stream_copy(hipStream_t st, void* dst, const void* src, size_t bytes)
 {
     const size_t n16 = bytes / 16;
     hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, st, (float4*)dst, (const float4*)src, n16);
+    return (int)hipGetLastError();
+}
+
+} // namespace chase_hip
+
+// =====================================================================================================================
+// O(N*n) streaming kernels.  All complex data is interleaved (re,im); where the operation acts identically on both
+// parts (real scalars) the kernels treat a column as md = m*ept doubles.
+// Reductions: one 256-thread workgroup per column, wave64 __shfl_down tree, then 4 partials through LDS.  The
+// summation order is fixed, so results are bitwise reproducible run to run (needed for replicated data).
+// =====================================================================================================================
+namespace chase_hip {
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// all threads of a 256-thread block call this; result valid in thread 0
+__device__ __forceinline__ double block_sum_256(double v, double* sm /*[4]*/)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    __syncthreads();
+    return r;
+}
+
+// H[i,i] += shift (real part for complex).  Reference: cuda/shiftDiagonal.cu:23-50, chase_cpu.hpp:384-389
+__global__ void shift_diag_kernel(double* __restrict__ H, long ld, int n, int ept, double shift)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) H[((long)i * ld + i) * ept] += shift;
+}
+
+// H[r[i], c[i]] += shift for a list of local (row, col) pairs.  Reference: cuda/shiftDiagonal.cu:100-149 (shift_mgpu)
+__global__ void shift_list_kernel(double* __restrict__ H, long ld, const int* __restrict__ rows,
+                                  const int* __restrict__ cols, int cnt, int ept, double shift)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) H[((long)cols[i] * ld + rows[i]) * ept] += shift;
+}
+
+// A[i,i] += sqrt(m) * eps * (*nrmf) with the shift read from device memory.  Reference: cuda/shiftDiagonal.cu:52-98
+__global__ void shift_diag_dev_kernel(double* __restrict__ A, long ld, int n, int ept, const double* __restrict__ nrmf,
+                                      double factor)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) A[((long)i * ld + i) * ept] += factor * nrmf[0];
+}
+
+// out[0] = sum_i |A[i,i]|.  Reference: cuda/absTrace.cu:113-167, cpu computeDiagonalAbsSum
+__global__ __launch_bounds__(256) void abs_trace_kernel(const double* __restrict__ A, long ld, int n, int ept,
+                                                        double* __restrict__ out)
+{
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double* p = A + ((long)i * ld + i) * ept;
+        s += (ept == 2) ? hypot(p[0], p[1]) : fabs(p[0]);
+    }
+    s = block_sum_256(s, sm);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+// strided 2-D copy (lacpy 'A').  Reference: cuda/lacpy.cu:62-530
+__global__ __launch_bounds__(256) void copy2d_kernel(const double* __restrict__ src, long lds_, double* __restrict__ dst,
+                                                     long ldd, long md, int ncols, int vec2)
+{
+    for (int j = blockIdx.y; j < ncols; j += gridDim.y) {
+        const double* s = src + (long)j * lds_;
+        double* d = dst + (long)j * ldd;
+        if (vec2) {
+            const long n2 = md >> 1;
+            for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long)gridDim.x * 256)
+                ((double2*)d)[i] = ((const double2*)s)[i];
+        } else {
+            for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < md; i += (long)gridDim.x * 256) d[i] = s[i];
+        }
+    }
+}
+
+// swap two columns.  Reference: chase_gpu.hpp:1003-1005 (cublasTswap), chase_cpu.hpp:820-830
+__global__ __launch_bounds__(256) void swap_kernel(double* __restrict__ a, double* __restrict__ b, long md)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < md; i += (long)gridDim.x * 256) {
+        const double t = a[i]; a[i] = b[i]; b[i] = t;
+    }
+}
+
+// out[j] = sum_i |W[i,j] - lambda[j] * V[i,j]|^2  (sqrt optional).  V == nullptr -> plain column norms.
+// Reference: cuda/residuals.cu:113-296 (one block per column), cpu/residuals.hpp:72-79 (axpy + nrm2)
+__global__ __launch_bounds__(256) void resid_norms_kernel(const double* __restrict__ W, long ldw,
+                                                          const double* __restrict__ V, long ldv,
+                                                          const double* __restrict__ lambda, long md,
+                                                          double* __restrict__ out, int do_sqrt)
+{
+    __shared__ double sm[4];
+    const int j = blockIdx.x;
+    const double* w = W + (long)j * ldw;
+    double s = 0.0;
+    if (V) {
+        const double* v = V + (long)j * ldv;
+        const double lam = lambda[j];
+        for (long i = threadIdx.x; i < md; i += 256) { const double r = w[i] - lam * v[i]; s += r * r; }
+    } else {
+        for (long i = threadIdx.x; i < md; i += 256) { const double r = w[i]; s += r * r; }
+    }
+    s = block_sum_256(s, sm);
+    if (threadIdx.x == 0) out[j] = do_sqrt ? sqrt(s) : s;
+}
+
+__global__ void sqrt_inplace_kernel(double* __restrict__ x, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = sqrt(x[i]);
+}
+
+// out[j] = x_j^H y_j  (complex: (re,im) pair; real: one double).  Reference: cuda/lanczos_kernels.cu batched_dot_product
+template <bool CPLX>
+__global__ __launch_bounds__(256) void col_dot_kernel(const double* __restrict__ X, long ldx, const double* __restrict__ Y,
+                                                      long ldy, int m, double* __restrict__ out)
+{
+    __shared__ double sm[4];
+    const int j = blockIdx.x;
+    if constexpr (CPLX) {
+        const double2* x = (const double2*)(X + (long)j * ldx);
+        const double2* y = (const double2*)(Y + (long)j * ldy);
+        double sr = 0.0, si = 0.0;
+        for (int i = threadIdx.x; i < m; i += 256) {
+            const double2 a = x[i], b = y[i];
+            sr += a.x * b.x + a.y * b.y;
+            si += a.x * b.y - a.y * b.x;
+        }
+        sr = block_sum_256(sr, sm);
+        si = block_sum_256(si, sm);
+        if (threadIdx.x == 0) { out[2 * j] = sr; out[2 * j + 1] = si; }
+    } else {
+        const double* x = X + (long)j * ldx;
+        const double* y = Y + (long)j * ldy;
+        double s = 0.0;
+        for (int i = threadIdx.x; i < m; i += 256) s += x[i] * y[i];
+        s = block_sum_256(s, sm);
+        if (threadIdx.x == 0) out[j] = s;
+    }
+}
+
+// Y_j += sgn * a_j * X_j with a_j read from device memory (complex a for CPLX unless a_is_real).
+// Reference: cuda/lanczos_kernels.cu fused_dot_axpy_negate / batched_axpy; batchedAxpyScalar (:161-210) when a_stride==0
+template <bool CPLX>
+__global__ __launch_bounds__(256) void col_axpy_kernel(const double* __restrict__ a, int a_is_real, int a_stride,
+                                                       double sgn, const double* __restrict__ X, long ldx,
+                                                       double* __restrict__ Y, long ldy, int m, int ncols)
+{
+    for (int j = blockIdx.y; j < ncols; j += gridDim.y) {
+        if constexpr (CPLX) {
+            double ar, ai;
+            if (a_is_real) { ar = sgn * a[(long)j * a_stride]; ai = 0.0; }
+            else { ar = sgn * a[2L * j * a_stride]; ai = sgn * a[2L * j * a_stride + 1]; }
+            const double2* x = (const double2*)(X + (long)j * ldx);
+            double2* y = (double2*)(Y + (long)j * ldy);
+            for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
+                const double2 xv = x[i]; double2 yv = y[i];
+                yv.x += ar * xv.x - ai * xv.y;
+                yv.y += ar * xv.y + ai * xv.x;
+                y[i] = yv;
+            }
+        } else {
+            const double av = sgn * a[(long)j * a_stride];
+            const double* x = X + (long)j * ldx;
+            double* y = Y + (long)j * ldy;
+            for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) y[i] += av * x[i];
+        }
+    }
+}
+
+// X_j *= (inv ? 1/a_j : a_j), a real, device resident.  Reference: cuda/lanczos_kernels.cu batched_scale / normalize_vectors
+__global__ __launch_bounds__(256) void col_scal_kernel(const double* __restrict__ a, int inv, double* __restrict__ X,
+                                                       long ldx, long md, int ncols)
+{
+    for (int j = blockIdx.y; j < ncols; j += gridDim.y) {
+        const double s = inv ? 1.0 / a[j] : a[j];
+        double* x = X + (long)j * ldx;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < md; i += (long)gridDim.x * 256) x[i] *= s;
+    }
+}
+
+// rows >= row0: X[i, j] *= s.  Reference: cuda/flipSign.cu (flipLowerHalfMatrixSign with s = -1, scaleLowerBlockRows)
+__global__ __launch_bounds__(256) void scale_rows_kernel(double* __restrict__ X, long ldx, long row0_d, long md,
+                                                         int ncols, double s)
+{
+    for (int j = blockIdx.y; j < ncols; j += gridDim.y) {
+        double* x = X + (long)j * ldx;
+        for (long i = row0_d + (long)blockIdx.x * 256 + threadIdx.x; i < md; i += (long)gridDim.x * 256) x[i] *= s;
+    }
+}
+
+// in-place complex conjugate.  Reference: cuda/conjugate.cu:21-70
+__global__ __launch_bounds__(256) void conj_kernel(double* __restrict__ X, long ldx_d, int m, int ncols)
+{
+    for (int j = blockIdx.y; j < ncols; j += gridDim.y) {
+        double* x = X + (long)j * ldx_d;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) x[2 * i + 1] = -x[2 * i + 1];
+    }
+}
+
+// pack / unpack the upper triangle of an n x n matrix into n(n+1)/2 elements (column by column).
+// Reference: cuda/lacpy.cu:837-1094 (halves the Gram all-reduce payload, nccl/cholqr.hpp:152-157)
+__global__ void pack_upper_kernel(const double* __restrict__ A, long lda, int n, int ept, double* __restrict__ P, int unpack,
+                                  double* __restrict__ Aout)
+{
+    const int j = blockIdx.x;                       // column
+    const long base = (long)j * (j + 1) / 2;
+    for (int i = threadIdx.x; i <= j; i += blockDim.x) {
+        for (int e = 0; e < ept; ++e) {
+            if (!unpack) P[(base + i) * ept + e] = A[((long)j * lda + i) * ept + e];
+            else Aout[((long)j * lda + i) * ept + e] = P[(base + i) * ept + e];
+        }
+    }
+}
+
+// A[i,j] = conj(A[j,i]) for i > j: rebuild the strictly-lower triangle from the upper one
+__global__ void mirror_upper_kernel(double* __restrict__ A, long lda, int n, int ept)
+{
+    const int j = blockIdx.x;
+    for (int i = j + 1 + threadIdx.x; i < n; i += blockDim.x) {
+        const double* s = A + ((long)i * lda + j) * ept;        // A[j,i] (upper)
+        double* d = A + ((long)j * lda + i) * ept;              // A[i,j] (lower)
+        d[0] = s[0];
+        if (ept == 2) d[1] = -s[1];
+    }
+}
+
+// dst[:, dst_idx[c]] = src[:, src_idx[c]] for c < cnt (batched column gather; applies the deferred Swap() permutation)
+__global__ __launch_bounds__(256) void copy_cols_indexed_kernel(const double* __restrict__ src, long lds_, double* __restrict__ dst,
+                                                                long ldd, long md, const int* __restrict__ src_idx,
+                                                                const int* __restrict__ dst_idx, int cnt)
+{
+    for (int c = blockIdx.y; c < cnt; c += gridDim.y) {
+        const double* s = src + (long)src_idx[c] * lds_;
+        double* d = dst + (long)dst_idx[c] * ldd;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < md; i += (long)gridDim.x * 256) d[i] = s[i];
+    }
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------------------
+static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+static inline dim3 grid2(long md, int ncols)
+{
+    unsigned gx = cdiv(md, 256 * 4); if (gx < 1) gx = 1; if (gx > 64) gx = 64;
+    unsigned gy = ncols < 1 ? 1 : (ncols > 1024 ? 1024 : ncols);
+    return dim3(gx, gy);
+}
+
+int shift_diag(hipStream_t st, double* H, long ld, int n, int ept, double shift)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(shift_diag_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, H, ld, n, ept, shift);
+    return (int)hipGetLastError();
+}
+int shift_list(hipStream_t st, double* H, long ld, const int* rows, const int* cols, int cnt, int ept, double shift)
+{
+    if (cnt <= 0) return 0;
+    hipLaunchKernelGGL(shift_list_kernel, dim3(cdiv(cnt, 256)), dim3(256), 0, st, H, ld, rows, cols, cnt, ept, shift);
+    return (int)hipGetLastError();
+}
+int shift_diag_dev(hipStream_t st, double* A, long ld, int n, int ept, const double* nrmf, double factor)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(shift_diag_dev_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, A, ld, n, ept, nrmf, factor);
+    return (int)hipGetLastError();
+}
+int abs_trace(hipStream_t st, const double* A, long ld, int n, int ept, double* out_dev)
+{
+    hipLaunchKernelGGL(abs_trace_kernel, dim3(1), dim3(256), 0, st, A, ld, n, ept, out_dev);
+    return (int)hipGetLastError();
+}
+int copy2d(hipStream_t st, const double* src, long ld_src_d, double* dst, long ld_dst_d, long md, int ncols)
+{
+    if (md <= 0 || ncols <= 0) return 0;
+    const int vec2 = ((md & 1) == 0) && ((ld_src_d & 1) == 0) && ((ld_dst_d & 1) == 0) &&
+                     (((uintptr_t)src & 15) == 0) && (((uintptr_t)dst & 15) == 0);
+    hipLaunchKernelGGL(copy2d_kernel, grid2(md, ncols), dim3(256), 0, st, src, ld_src_d, dst, ld_dst_d, md, ncols, vec2);
+    return (int)hipGetLastError();
+}
+int copy_cols_indexed(hipStream_t st, const double* src, long ld_src_d, double* dst, long ld_dst_d, long md,
+                      const int* src_idx_dev, const int* dst_idx_dev, int cnt)
+{
+    if (cnt <= 0 || md <= 0) return 0;
+    hipLaunchKernelGGL(copy_cols_indexed_kernel, grid2(md, cnt), dim3(256), 0, st, src, ld_src_d, dst, ld_dst_d, md,
+                       src_idx_dev, dst_idx_dev, cnt);
+    return (int)hipGetLastError();
+}
+int swap_cols(hipStream_t st, double* a, double* b, long md)
+{
+    if (md <= 0 || a == b) return 0;
+    unsigned g = cdiv(md, 256 * 4); if (g > 256) g = 256;
+    hipLaunchKernelGGL(swap_kernel, dim3(g), dim3(256), 0, st, a, b, md);
+    return (int)hipGetLastError();
+}
+int resid_norms(hipStream_t st, const double* W, long ldw_d, const double* V, long ldv_d, const double* lambda_dev,
+                long md, int ncols, double* out_dev, int do_sqrt)
+{
+    if (ncols <= 0) return 0;
+    hipLaunchKernelGGL(resid_norms_kernel, dim3(ncols), dim3(256), 0, st, W, ldw_d, V, ldv_d, lambda_dev, md, out_dev,
+                       do_sqrt);
+    return (int)hipGetLastError();
+}
+int sqrt_inplace(hipStream_t st, double* x, int n)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(sqrt_inplace_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, x, n);
+    return (int)hipGetLastError();
+}
+int col_dot(hipStream_t st, bool cplx, const double* X, long ldx_d, const double* Y, long ldy_d, int m, int ncols,
+            double* out_dev)
+{
+    if (ncols <= 0) return 0;
+    if (cplx) hipLaunchKernelGGL(col_dot_kernel<true>, dim3(ncols), dim3(256), 0, st, X, ldx_d, Y, ldy_d, m, out_dev);
+    else      hipLaunchKernelGGL(col_dot_kernel<false>, dim3(ncols), dim3(256), 0, st, X, ldx_d, Y, ldy_d, m, out_dev);
+    return (int)hipGetLastError();
+}
+int col_axpy(hipStream_t st, bool cplx, const double* a_dev, int a_is_real, int a_stride, double sgn, const double* X,
+             long ldx_d, double* Y, long ldy_d, int m, int ncols)
+{
+    if (ncols <= 0 || m <= 0) return 0;
+    const dim3 g = grid2(m, ncols);
+    if (cplx) hipLaunchKernelGGL(col_axpy_kernel<true>, g, dim3(256), 0, st, a_dev, a_is_real, a_stride, sgn, X, ldx_d, Y, ldy_d, m, ncols);
+    else      hipLaunchKernelGGL(col_axpy_kernel<false>, g, dim3(256), 0, st, a_dev, a_is_real, a_stride, sgn, X, ldx_d, Y, ldy_d, m, ncols);
+    return (int)hipGetLastError();
+}
+int col_scal(hipStream_t st, const double* a_dev, int inv, double* X, long ldx_d, long md, int ncols)
+{
+    if (ncols <= 0 || md <= 0) return 0;
+    hipLaunchKernelGGL(col_scal_kernel, grid2(md, ncols), dim3(256), 0, st, a_dev, inv, X, ldx_d, md, ncols);
+    return (int)hipGetLastError();
+}
+int scale_rows(hipStream_t st, double* X, long ldx_d, long row0_d, long md, int ncols, double s)
+{
+    if (ncols <= 0 || md <= row0_d) return 0;
+    hipLaunchKernelGGL(scale_rows_kernel, grid2(md - row0_d, ncols), dim3(256), 0, st, X, ldx_d, row0_d, md, ncols, s);
+    return (int)hipGetLastError();
+}
+int conj_inplace(hipStream_t st, double* X, long ldx_d, int m, int ncols)
+{
+    if (ncols <= 0 || m <= 0) return 0;
+    hipLaunchKernelGGL(conj_kernel, grid2(m, ncols), dim3(256), 0, st, X, ldx_d, m, ncols);
+    return (int)hipGetLastError();
+}
+int pack_upper(hipStream_t st, const double* A, long lda, int n, int ept, double* P)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(pack_upper_kernel, dim3(n), dim3(128), 0, st, A, lda, n, ept, P, 0, (double*)nullptr);
+    return (int)hipGetLastError();
+}
+int unpack_upper(hipStream_t st, double* P, int n, int ept, double* A, long lda)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(pack_upper_kernel, dim3(n), dim3(128), 0, st, (const double*)nullptr, lda, n, ept, P, 1, A);
+    return (int)hipGetLastError();
+}
+int mirror_upper(hipStream_t st, double* A, long lda, int n, int ept)
+{
+    if (n <= 1) return 0;
+    hipLaunchKernelGGL(mirror_upper_kernel, dim3(n), dim3(128), 0, st, A, lda, n, ept);
     return (int)hipGetLastError();
 }
 

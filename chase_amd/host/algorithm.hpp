@@ -1,0 +1,351 @@
+// algorithm.hpp — host-side ChASE driver: subspace iteration with a Chebyshev filter, QR, Rayleigh-Ritz, residual
+// check and locking.  Scalar logic only; every touch of matrix data goes through the Kernel's ChaseBase virtuals.
+//
+// The reference driver (algorithm/algorithm.inc) cannot travel to the GPU box, so this is an own restatement that issues
+// the SAME sequence of virtual calls with the SAME scalar arguments:
+//   solve        <- algorithm/algorithm.inc:1376-1788
+//   filter       <- :942-1009      (three-term Chebyshev recurrence, columns retire from the left)
+//   calc_degrees <- :136-193       (per-column degree from residual and rho, even, exchange sort)
+//   locking      <- :519-578       (ascending Ritz order, early-lock of stagnating pairs)
+//   lanczos      <- :1067-1214     (DoS estimate of the lower filter bound)
+// Kernel is any type with the ChaseBase<T> surface (chase_amd::ChaseBase<T> here, chase::ChaseBase<T> in ChASE).
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstddef>
+#include <cstdio>
+#include <limits>
+#include <numeric>
+#include <string>
+#include <vector>
+#include "interface.hpp"
+
+namespace chase_amd {
+
+struct SolveStats {
+    std::size_t iterations = 0;
+    std::size_t filtered_vecs = 0;      // sum over HEMM calls of active columns (performance.hpp:559-563)
+    std::size_t lanczos_vecs = 0;
+    std::size_t locked = 0;
+    double t_all = 0, t_init = 0, t_lanczos = 0, t_filter = 0, t_qr = 0, t_rr = 0, t_resid = 0;
+    double lowerb = 0, upperb = 0, lambda = 0;
+    std::vector<std::size_t> iter_unconverged, iter_filtered, iter_maxdeg;
+};
+
+// optional observer of the virtual-call sequence (tests compare it against the oracle's trace)
+struct CallTrace {
+    std::vector<std::string> lines;
+    bool enabled = false;
+    void add(const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+};
+inline void CallTrace::add(const char* fmt, ...)
+{
+    if (!enabled) return;
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    lines.emplace_back(buf);
+}
+
+template <class T, class Kernel>
+class Algorithm {
+public:
+    using R = Base<T>;
+    using clock = std::chrono::steady_clock;
+    static double since(clock::time_point t0) { return std::chrono::duration<double>(clock::now() - t0).count(); }
+
+    // growth factor of the Chebyshev polynomial outside [-1, 1]
+    static R rho_of(R t)
+    {
+        const R s = std::sqrt(std::abs(t * t - 1));
+        return std::max(std::abs(t - s), std::abs(t + s));
+    }
+
+    static std::size_t calc_degrees(Kernel* k, std::size_t unconverged, std::size_t nex, R upperb, R lowerb, R tol,
+                                    R* ritzv, R* resid, std::size_t* degrees, std::size_t locked)
+    {
+        auto& cfg = k->GetConfig();
+        const R c = (upperb + lowerb) / 2, e = (upperb - lowerb) / 2;
+        const std::size_t active = unconverged - nex;
+        for (std::size_t i = 0; i < active; ++i) {
+            const R rho = rho_of((ritzv[i] - c) / e);
+            const std::size_t d = (std::size_t)std::ceil(std::abs(std::log(resid[i] / tol) / std::log(rho)));
+            degrees[i] = std::min(d + cfg.GetDegExtra(), cfg.GetMaxDeg());
+        }
+        for (std::size_t i = active; i < unconverged; ++i) degrees[i] = degrees[active - 1];
+        for (std::size_t i = 0; i < unconverged; ++i) degrees[i] += degrees[i] % 2;
+        // exchange sort by ascending degree; the permutation is mirrored on the vectors through Swap()
+        for (std::size_t j = 0; j + 1 < unconverged; ++j)
+            for (std::size_t i = j; i < unconverged; ++i)
+                if (degrees[i] < degrees[j]) {
+                    std::swap(degrees[i], degrees[j]);
+                    std::swap(ritzv[i], ritzv[j]);
+                    std::swap(resid[i], resid[j]);
+                    k->Swap(i + locked, j + locked);
+                }
+        return degrees[unconverged - 1];
+    }
+
+    static std::size_t locking(Kernel* k, std::size_t candidates, R tol, R* ritzv, R* resid, R* residLast,
+                               std::vector<R>* early, std::size_t locked)
+    {
+        std::vector<int> order(candidates);
+        std::iota(order.begin(), order.end(), 0);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return ritzv[a] < ritzv[b]; });
+        const bool sym = k->isSym();
+        std::size_t converged = 0;
+        for (std::size_t pos = 0; pos < candidates; ++pos) {
+            const std::size_t j = (std::size_t)order[pos];      // NB: not refreshed after swaps (reference behaviour)
+            const bool stagnating = sym && resid[j] >= residLast[j] && resid[j] < 100.0 * tol;
+            if (resid[j] <= tol || stagnating) {
+                if (resid[j] > tol) early->push_back(resid[j]);
+                if (j != converged) {
+                    std::swap(resid[j], resid[converged]);
+                    std::swap(residLast[j], residLast[converged]);
+                    std::swap(ritzv[j], ritzv[converged]);
+                    k->Swap(j + locked, converged + locked);
+                }
+                ++converged;
+            }
+        }
+        return converged;
+    }
+
+    static std::size_t filter(Kernel* k, std::size_t n, std::size_t unprocessed, std::size_t deg,
+                              const std::size_t* degrees, R lambda_1, R lower, R upper, CallTrace* tr = nullptr)
+    {
+        const R c = (upper + lower) / 2, e = (upper - lower) / 2;
+        const R sigma_1 = e / (lambda_1 - c);
+        R sigma = sigma_1;
+        std::size_t offset = 0, done = 0, Av = 0, next = 0;   // next: first column still being filtered
+
+        k->FilterPhaseStart();
+        k->Shift(T(-c));
+        T alpha = T(sigma_1 / e), beta = T(0.0);
+        if (tr) tr->add("HEMM %zu %.17g %.17g %zu", unprocessed, (double)std::real(alpha), (double)std::real(beta), offset / n);
+        k->HEMM(unprocessed, alpha, beta, offset / n);
+        Av += unprocessed;
+        ++done;
+        while (unprocessed != 0 && degrees[next] <= done) { ++next; --unprocessed; offset += n; }
+
+        for (std::size_t i = 2; i <= deg; ++i) {
+            const R sigma_new = 1.0 / (2.0 / sigma_1 - sigma);
+            alpha = T(2.0 * sigma_new / e);
+            beta = T(-sigma * sigma_new);
+            if (tr) tr->add("HEMM %zu %.17g %.17g %zu", unprocessed, (double)std::real(alpha), (double)std::real(beta), offset / n);
+            k->HEMM(unprocessed, alpha, beta, offset / n);
+            sigma = sigma_new;
+            Av += unprocessed;
+            ++done;
+            while (unprocessed != 0 && degrees[next] <= done) { ++next; --unprocessed; offset += n; }
+        }
+        k->Shift(T(+c), true);
+        k->FilterPhaseEnd();
+        return Av;
+    }
+
+    // Lanczos + density-of-states estimate of the filter's lower bound; returns the number of extracted vectors.
+    static std::size_t lanczos(Kernel* k, int N, int numvec, int m, int nevex, R* upperb, bool mode, R* ritzv)
+    {
+        if (!mode) {
+            k->Lanczos((std::size_t)m, upperb);
+            return 0;
+        }
+        std::vector<R> Theta((std::size_t)numvec * m, 0), Tau((std::size_t)numvec * m, 0), ritzV((std::size_t)m * m, 0);
+        k->Lanczos((std::size_t)m, (std::size_t)numvec, upperb, Theta.data(), Tau.data(), ritzV.data());
+
+        std::vector<double> sorted(Theta.begin(), Theta.end());
+        std::sort(sorted.begin(), sorted.end());
+        const R lambda = (R)sorted[0];
+        R lowerb = 0;                                   // (reference leaves it uninitialised if the scan never trips)
+
+        const double sigma = 0.25, threshold = 2 * sigma * sigma / 10;
+        const double search = (double)nevex / (double)N;
+        auto G = [&](double x) { return 0.5 * (1 + std::erf(x / std::sqrt(2 * sigma * sigma))); };
+        std::size_t bound = (std::size_t)m;
+        if (k->isPseudoHerm()) bound /= 2;
+        const long total = (long)numvec * (long)bound;
+        double prev = 0;
+        for (long i = 0; i + 1 < total; ++i) {
+            double curr = 0;
+            for (long j = 0; j < total; ++j) {
+                if (sorted[i] < Theta[j] - threshold) continue;
+                else if (sorted[i] > Theta[j] + threshold) curr += Tau[j];
+                else curr += Tau[j] * G(sorted[i] - Theta[j]);
+            }
+            curr /= numvec;
+            if (curr > search) {
+                if (std::abs(curr - search) < std::abs(prev - search))
+                    lowerb = (R)((i + 1 < total) ? sorted[i + 1] : sorted[i]);
+                else
+                    lowerb = (R)sorted[i];
+                break;
+            }
+            prev = curr;
+        }
+
+        // vectors of the LAST run whose Ritz value lies below lowerb become approximate eigenvectors
+        int idx = 0;
+        for (int i = 0; i < m; ++i)
+            if (Theta[(std::size_t)(numvec - 1) * m + i] > lowerb) { idx = i - 1; break; }
+        if (idx > 0) {
+            std::vector<T> ritzVc((std::size_t)m * m);
+            for (std::size_t i = 0; i < ritzVc.size(); ++i) ritzVc[i] = T(ritzV[i]);
+            k->LanczosDos((std::size_t)idx, (std::size_t)m, ritzVc.data());
+        }
+        for (int i = 0; i < idx; ++i) ritzv[i] = Theta[(std::size_t)(numvec - 1) * m + i];
+        for (int i = std::max(idx, 0); i < nevex - 1; ++i) ritzv[i] = lambda;
+        ritzv[nevex - 1] = lowerb;
+        for (int i = 1; i < idx; ++i) {                 // intersperse the extracted vectors through the block
+            const int j = i * (nevex / idx);
+            k->Swap((std::size_t)i, (std::size_t)j);
+            std::swap(ritzv[i], ritzv[j]);
+        }
+        return (std::size_t)std::max(idx, 0);
+    }
+
+    static void solve(Kernel* k, SolveStats* st = nullptr, CallTrace* tr = nullptr)
+    {
+        SolveStats local;
+        if (!st) st = &local;
+        auto t_all0 = clock::now();
+        auto& cfg = k->GetConfig();
+        k->Start();
+        const std::size_t N = cfg.GetN(), nev = cfg.GetNev(), nex = cfg.GetNex(), nevex = nev + nex;
+        const double tol = cfg.GetTol();
+        R* const resid_all = k->GetResid();
+        R* const ritzv_all = k->GetRitzv();
+        std::vector<std::size_t> degrees_all(nevex);
+        std::vector<R> residLast_all(nevex, std::numeric_limits<R>::max());
+        std::vector<R> early;
+        for (std::size_t i = 0; i < nevex; ++i) resid_all[i] = std::numeric_limits<R>::max();
+
+        std::size_t deg = cfg.GetDeg();
+        deg += deg % 2;
+        deg = std::min(deg, cfg.GetMaxDeg());
+        std::fill(degrees_all.begin(), degrees_all.end(), deg);
+
+        auto t0 = clock::now();
+        const bool random = !cfg.UseApprox();
+        if (tr) tr->add("initVecs %d", (int)random);
+        k->initVecs(random);
+        if (random) {
+            if (tr) tr->add("QR 0 1");
+            k->QR(0, (R)1.0);
+        }
+        st->t_init = since(t0);
+
+        t0 = clock::now();
+        std::size_t lanczos_iter = std::min(nevex, std::min(N / 2, cfg.GetLanczosIter()));
+        if (lanczos_iter % 2 != 0) {                    // even number of Ritz values (pseudo-Hermitian symmetry)
+            cfg.SetLanczosIter(lanczos_iter - 1);
+            lanczos_iter = cfg.GetLanczosIter();
+        }
+        R upperb = 0;
+        if (tr) tr->add("Lanczos %zu %zu", lanczos_iter, cfg.GetNumLanczos());
+        lanczos(k, (int)N, (int)cfg.GetNumLanczos(), (int)lanczos_iter, (int)nevex, &upperb, random,
+                random ? ritzv_all : nullptr);
+        st->lanczos_vecs = random ? lanczos_iter * cfg.GetNumLanczos() : lanczos_iter;
+        st->t_lanczos = since(t0);
+
+        std::size_t locked = 0, unconverged = nevex, iteration = 0;
+        R lowerb = *std::max_element(ritzv_all, ritzv_all + unconverged);
+        const R lambda = *std::min_element(ritzv_all, ritzv_all + nevex);     // never updated afterwards
+        lowerb = lowerb * cfg.GetDecayingRate();
+        if (tr) tr->add("bounds %.10e %.10e %.10e", (double)lambda, (double)lowerb, (double)upperb);
+
+        while (unconverged > nex && iteration < cfg.GetMaxIter()) {
+            R* ritzv = ritzv_all + locked;
+            R* resid = resid_all + locked;
+            R* residLast = residLast_all.data() + locked;
+            std::size_t* degrees = degrees_all.data() + locked;
+
+            bool all_small = true;
+            for (std::size_t i = 0; i < unconverged; ++i)
+                if (resid[i] > 5e-1) { all_small = false; break; }
+            if (k->isSym() && all_small) lowerb = ritzv[unconverged - 1];
+            if (lowerb > upperb) {
+                std::fprintf(stderr, "chase_amd: lowerb > upperb, clamping\n");
+                lowerb = upperb;
+            }
+            if (k->isSym())
+                for (std::size_t i = 0; i < unconverged; ++i) residLast[i] = std::min(residLast[i], resid[i]);
+
+            if (cfg.DoOptimization() && iteration != 0)
+                deg = calc_degrees(k, unconverged, nex, upperb, lowerb, (R)tol, ritzv, resid, degrees, locked);
+
+            t0 = clock::now();
+            if (tr) tr->add("filter it=%zu unconverged=%zu deg=%zu", iteration, unconverged, deg);
+            const std::size_t Av = filter(k, N, unconverged, deg, degrees, lambda, lowerb, upperb, tr);
+            st->filtered_vecs += Av;
+            st->t_filter += since(t0);
+
+            // condition-number estimate of the filtered block steers the CholQR variant
+            const R cc = (upperb + lowerb) / 2, ee = (upperb - lowerb) / 2;
+            const R t_1 = (k->GetRitzv()[0] - cc) / ee, t_k = (ritzv[0] - cc) / ee;
+            const R rho_1 = std::max(std::abs(t_1 - std::sqrt(t_1 * t_1 - 1)), std::abs(t_1 + std::sqrt(t_1 * t_1 - 1)));
+            const R rho_k = std::max(std::abs(t_k - std::sqrt(t_k * t_k - 1)), std::abs(t_k + std::sqrt(t_k * t_k - 1)));
+            const std::size_t dmax = *std::max_element(degrees, degrees + (nevex - locked));
+            const R cond = std::pow(rho_k, (R)degrees[0]) * std::pow(rho_1, (R)(dmax - degrees[0]));
+
+            t0 = clock::now();
+            if (tr) tr->add("QR %zu %.6e", locked, (double)cond);
+            k->QR(locked, cond);
+            st->t_qr += since(t0);
+
+            t0 = clock::now();
+            if (tr) tr->add("RR %zu", unconverged);
+            k->RR(ritzv, unconverged);
+            st->t_rr += since(t0);
+
+            t0 = clock::now();
+            if (tr) tr->add("Resd %zu", locked);
+            k->Resd(ritzv, resid, locked);
+            st->t_resid += since(t0);
+
+            const std::size_t new_converged =
+                locking(k, unconverged - nex, (R)tol, ritzv, resid, residLast, &early, locked);
+            if (tr) tr->add("Lock %zu", new_converged);
+            k->Lock(new_converged);
+
+            st->iter_unconverged.push_back(unconverged);
+            st->iter_filtered.push_back(Av);
+            st->iter_maxdeg.push_back(deg);
+            locked += new_converged;
+            unconverged -= new_converged;
+            ++iteration;
+        }
+
+        // final ordering of the nev wanted pairs by eigenvalue: follow the cycles of the sorting permutation
+        std::vector<std::size_t> perm(nev);
+        std::iota(perm.begin(), perm.end(), 0);
+        std::sort(perm.begin(), perm.end(), [&](std::size_t a, std::size_t b) { return ritzv_all[a] < ritzv_all[b]; });
+        std::vector<bool> seen(nev, false);
+        for (std::size_t i = 0; i < nev; ++i) {
+            if (seen[i] || perm[i] == i) continue;
+            std::vector<std::size_t> cyc;
+            for (std::size_t cur = i; !seen[cur]; cur = perm[cur]) { seen[cur] = true; cyc.push_back(cur); }
+            const R r0 = ritzv_all[cyc[0]], s0 = resid_all[cyc[0]];
+            for (std::size_t q = 0; q + 1 < cyc.size(); ++q) {
+                ritzv_all[cyc[q]] = ritzv_all[cyc[q + 1]];
+                resid_all[cyc[q]] = resid_all[cyc[q + 1]];
+            }
+            ritzv_all[cyc.back()] = r0;
+            resid_all[cyc.back()] = s0;
+            for (std::size_t q = 0; q + 1 < cyc.size(); ++q) k->Swap(cyc[q], cyc[q + 1]);
+        }
+        k->set_early_locked_residuals(early);
+        k->End();
+
+        st->iterations = iteration;
+        st->locked = locked;
+        st->lowerb = lowerb; st->upperb = upperb; st->lambda = lambda;
+        st->t_all = since(t_all0);
+    }
+};
+
+} // namespace chase_amd

@@ -1,0 +1,233 @@
+// solver_capi.cpp — C entry points of the host solver: construct a ChaseHip<T> Impl, configure, solve, and drive the
+// ChaseBase virtuals one by one (tests exercise every virtual through this surface, like the reference's
+// tests/linalg unit tests do for its Impl kernels).  Declared in include/chase_hip_solver.h.
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include "../../include/chase_hip.h"
+#include "../../include/chase_hip_solver.h"
+#include "algorithm.hpp"
+#include "chase_hip_impl.hpp"
+
+namespace chase_hip { int set_error(int code, const char* what); }
+using namespace chase_amd;
+
+struct chase_hip_solver {
+    int cplx = 0;
+    std::unique_ptr<ChaseHip<double>> d;
+    std::unique_ptr<ChaseHip<std::complex<double>>> z;
+    SolveStats stats;
+    CallTrace trace;
+    std::string trace_text;
+};
+
+namespace {
+template <class F>
+int guarded(const char* where, F&& f)
+{
+    try {
+        f();
+        return 0;
+    } catch (const HipStatusError& e) {
+        chase_hip::set_error(e.code, e.what());
+        return e.code;
+    } catch (const std::invalid_argument& e) {
+        return chase_hip::set_error(CHASE_HIP_EINVAL, (std::string(where) + ": " + e.what()).c_str());
+    } catch (const std::exception& e) {
+        return chase_hip::set_error(CHASE_HIP_EINVAL, (std::string(where) + ": " + e.what()).c_str());
+    }
+}
+#define DISPATCH(s, expr)                                                                                              \
+    do {                                                                                                               \
+        if ((s)->cplx) { auto& k = *(s)->z; expr; } else { auto& k = *(s)->d; expr; }                                  \
+    } while (0)
+} // namespace
+
+extern "C" {
+
+int chase_hip_solver_create(chase_hip_solver** out, chase_hip_ctx* ctx, int cplx, size_t N, size_t nev, size_t nex,
+                            void* H, size_t ldh, void* V, size_t ldv, double* ritzv, int h_on_device)
+{
+    if (!out || !ctx || !H || !V || !ritzv) return chase_hip::set_error(CHASE_HIP_EINVAL, "solver_create: NULL argument");
+    auto s = std::make_unique<chase_hip_solver>();
+    s->cplx = cplx ? 1 : 0;
+    int rc = guarded("solver_create", [&] {
+        if (cplx)
+            s->z = std::make_unique<ChaseHip<std::complex<double>>>(ctx, N, nev, nex, (std::complex<double>*)H, ldh,
+                                                                    (std::complex<double>*)V, ldv, ritzv,
+                                                                    h_on_device != 0);
+        else
+            s->d = std::make_unique<ChaseHip<double>>(ctx, N, nev, nex, (double*)H, ldh, (double*)V, ldv, ritzv,
+                                                      h_on_device != 0);
+    });
+    if (rc) return rc;
+    *out = s.release();
+    return 0;
+}
+
+int chase_hip_solver_destroy(chase_hip_solver* s)
+{
+    delete s;
+    return 0;
+}
+
+int chase_hip_solver_set(chase_hip_solver* s, const char* key, double v)
+{
+    if (!s || !key) return chase_hip::set_error(CHASE_HIP_EINVAL, "solver_set: NULL argument");
+    const std::string name(key);
+    int rc = 0;
+    DISPATCH(s, {
+        auto& c = k.GetConfig();
+        if (name == "tol") c.SetTol(v);
+        else if (name == "deg") c.SetDeg((size_t)v);
+        else if (name == "maxdeg") c.SetMaxDeg((size_t)v);
+        else if (name == "degextra") c.SetDegExtra((size_t)v);
+        else if (name == "maxiter") c.SetMaxIter((size_t)v);
+        else if (name == "lanczositer") c.SetLanczosIter((size_t)v);
+        else if (name == "numlanczos") c.SetNumLanczos((size_t)v);
+        else if (name == "opt") c.SetOpt(v != 0);
+        else if (name == "approx") c.SetApprox(v != 0);
+        else if (name == "cholqr") c.SetCholQR(v != 0);
+        else if (name == "decayingrate") c.SetDecayingRate((float)v);
+        else rc = chase_hip::set_error(CHASE_HIP_EINVAL, "solver_set: unknown key");
+    });
+    return rc;
+}
+
+int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* out)
+{
+    if (!s || !key || !out) return chase_hip::set_error(CHASE_HIP_EINVAL, "solver_get: NULL argument");
+    const std::string name(key);
+    int rc = 0;
+    DISPATCH(s, {
+        auto& c = k.GetConfig();
+        if (name == "tol") *out = c.GetTol();
+        else if (name == "deg") *out = (double)c.GetDeg();
+        else if (name == "maxdeg") *out = (double)c.GetMaxDeg();
+        else if (name == "degextra") *out = (double)c.GetDegExtra();
+        else if (name == "maxiter") *out = (double)c.GetMaxIter();
+        else if (name == "lanczositer") *out = (double)c.GetLanczosIter();
+        else if (name == "numlanczos") *out = (double)c.GetNumLanczos();
+        else if (name == "opt") *out = c.DoOptimization();
+        else if (name == "approx") *out = c.UseApprox();
+        else if (name == "cholqr") *out = c.DoCholQR();
+        else if (name == "decayingrate") *out = c.GetDecayingRate();
+        else if (name == "locked") *out = (double)k.locked();
+        else if (name == "qr_variant") *out = (double)k.last_qr_variant();
+        else if (name == "filter_ms") *out = k.filter_ms();
+        else rc = chase_hip::set_error(CHASE_HIP_EINVAL, "solver_get: unknown key");
+    });
+    return rc;
+}
+
+int chase_hip_solver_solve(chase_hip_solver* s, int record_trace)
+{
+    if (!s) return chase_hip::set_error(CHASE_HIP_EINVAL, "solver_solve: NULL solver");
+    s->stats = SolveStats();
+    s->trace.lines.clear();
+    s->trace.enabled = record_trace != 0;
+    return guarded("solve", [&] {
+        if (s->cplx) Algorithm<std::complex<double>, ChaseHip<std::complex<double>>>::solve(s->z.get(), &s->stats, &s->trace);
+        else Algorithm<double, ChaseHip<double>>::solve(s->d.get(), &s->stats, &s->trace);
+    });
+}
+
+int chase_hip_solver_stats(chase_hip_solver* s, chase_hip_stats* o)
+{
+    if (!s || !o) return chase_hip::set_error(CHASE_HIP_EINVAL, "solver_stats: NULL argument");
+    const SolveStats& t = s->stats;
+    o->iterations = t.iterations; o->filtered_vecs = t.filtered_vecs; o->lanczos_vecs = t.lanczos_vecs;
+    o->locked = t.locked;
+    o->t_all = t.t_all; o->t_init = t.t_init; o->t_lanczos = t.t_lanczos; o->t_filter = t.t_filter; o->t_qr = t.t_qr;
+    o->t_rr = t.t_rr; o->t_resid = t.t_resid;
+    o->lowerb = t.lowerb; o->upperb = t.upperb; o->lambda = t.lambda;
+    double fm = 0;
+    chase_hip_solver_get(s, "filter_ms", &fm);
+    o->filter_ms_device = fm;
+    return 0;
+}
+
+const double* chase_hip_solver_resid(chase_hip_solver* s)
+{
+    if (!s) return nullptr;
+    const double* r = nullptr;
+    DISPATCH(s, r = k.GetResid());
+    return r;
+}
+
+const char* chase_hip_solver_trace(chase_hip_solver* s)
+{
+    if (!s) return "";
+    s->trace_text.clear();
+    for (const auto& l : s->trace.lines) { s->trace_text += l; s->trace_text += '\n'; }
+    return s->trace_text.c_str();
+}
+
+/* ---- the ChaseBase virtuals, one entry point each (algorithm/interface.hpp:60-433) ---------------------------- */
+int chase_hip_op_start(chase_hip_solver* s) { return guarded("Start", [&] { DISPATCH(s, k.Start()); }); }
+int chase_hip_op_end(chase_hip_solver* s) { return guarded("End", [&] { DISPATCH(s, k.End()); }); }
+int chase_hip_op_initvecs(chase_hip_solver* s, int random)
+{
+    return guarded("initVecs", [&] { DISPATCH(s, k.initVecs(random != 0)); });
+}
+int chase_hip_op_shift(chase_hip_solver* s, double c, int isunshift)
+{
+    return guarded("Shift", [&] {
+        if (s->cplx) s->z->Shift(std::complex<double>(c, 0), isunshift != 0);
+        else s->d->Shift(c, isunshift != 0);
+    });
+}
+int chase_hip_op_hemm(chase_hip_solver* s, size_t block, const double* alpha, const double* beta, size_t offset_left,
+                      size_t offset_right)
+{
+    return guarded("HEMM", [&] {
+        if (s->cplx)
+            s->z->HEMM(block, std::complex<double>(alpha[0], alpha[1]), std::complex<double>(beta[0], beta[1]),
+                       offset_left, offset_right);
+        else s->d->HEMM(block, alpha[0], beta[0], offset_left, offset_right);
+    });
+}
+int chase_hip_op_qr(chase_hip_solver* s, size_t fixednev, double cond)
+{
+    return guarded("QR", [&] { DISPATCH(s, k.QR(fixednev, cond)); });
+}
+int chase_hip_op_rr(chase_hip_solver* s, double* ritzv, size_t block)
+{
+    return guarded("RR", [&] { DISPATCH(s, k.RR(ritzv, block)); });
+}
+int chase_hip_op_resd(chase_hip_solver* s, double* ritzv, double* resd, size_t fixednev)
+{
+    return guarded("Resd", [&] { DISPATCH(s, k.Resd(ritzv, resd, fixednev)); });
+}
+int chase_hip_op_swap(chase_hip_solver* s, size_t i, size_t j) { return guarded("Swap", [&] { DISPATCH(s, k.Swap(i, j)); }); }
+int chase_hip_op_lock(chase_hip_solver* s, size_t n) { return guarded("Lock", [&] { DISPATCH(s, k.Lock(n)); }); }
+int chase_hip_op_lanczos(chase_hip_solver* s, size_t M, size_t numvec, double* upperb, double* ritzv, double* Tau,
+                         double* ritzV)
+{
+    return guarded("Lanczos", [&] {
+        if (numvec == 0) DISPATCH(s, k.Lanczos(M, upperb));
+        else DISPATCH(s, k.Lanczos(M, numvec, upperb, ritzv, Tau, ritzV));
+    });
+}
+int chase_hip_op_lanczos_dos(chase_hip_solver* s, size_t idx, size_t m, void* ritzVc)
+{
+    return guarded("LanczosDos", [&] {
+        if (s->cplx) s->z->LanczosDos(idx, m, (std::complex<double>*)ritzVc);
+        else s->d->LanczosDos(idx, m, (double*)ritzVc);
+    });
+}
+int chase_hip_op_check_symmetry(chase_hip_solver* s, int* is_sym)
+{
+    return guarded("checkSymmetryEasy", [&] { DISPATCH(s, *is_sym = k.checkSymmetryEasy() ? 1 : 0); });
+}
+/* copies the current device V1 (N x nevex) to a host buffer without ending the solve (tests) */
+int chase_hip_solver_peek_v(chase_hip_solver* s, chase_hip_ctx* ctx, void* host, size_t ldh)
+{
+    return guarded("peek_v", [&] {
+        DISPATCH(s, hip_ok(chase_hip_download_matrix(ctx, s->cplx, (int)k.GetN(), (int)k.GetRitzvBlockSize(),
+                                                     k.device_V1(), (long)k.GetN(), host, (long)ldh), "download"));
+    });
+}
+
+} // extern "C"

@@ -70,6 +70,72 @@ int chase_hip_mfma_f64_peak(chase_hip_ctx* ctx, double* tflops);
 /* streaming-copy probe: achieved HBM GB/s for a bytes-sized device-to-device float4 copy */
 int chase_hip_hbm_copy_peak(chase_hip_ctx* ctx, size_t bytes, double* gbps);
 
+/* ---- host LAPACK provider (HEEVD / STEMR stay on the host per the north star) --------------------------------- */
+int chase_hip_set_lapack_lib(const char* path);   /* optional explicit LP64 LAPACK shared library */
+const char* chase_hip_lapack_provider(void);      /* path of the bound provider ("" if none) */
+int chase_hip_set_host_threads(int n);
+
+/* ---- O(N*n) kernels; cplx = 0 (fp64) or 1 (complex fp64); all matrix pointers are device pointers -------------- */
+/* H[i,i] += shift (real part).  Replaces chase_cpu.hpp:384-389 / cuda/shiftDiagonal.cu:23-50 */
+int chase_hip_shift_diag(chase_hip_ctx* ctx, int cplx, int n, void* H, long ldh, double shift);
+/* H[rows[i], cols[i]] += shift for precomputed local diagonal positions (device int arrays).
+ * Replaces cuda/shiftDiagonal.cu:100-149 + Impl/pchase_gpu/pchase_gpu.hpp:340-409 */
+int chase_hip_shift_list(chase_hip_ctx* ctx, int cplx, void* H, long ldh, const int* rows_dev, const int* cols_dev,
+                         int cnt, double shift);
+/* B = A (lacpy 'A').  Replaces cuda/lacpy.cu:503-835 */
+int chase_hip_lacpy(chase_hip_ctx* ctx, int cplx, int m, int n, const void* A, long lda, void* B, long ldb);
+/* swap columns i and j of V.  Replaces chase_gpu.hpp:1003-1005 (cublasTswap) */
+int chase_hip_swap_cols(chase_hip_ctx* ctx, int cplx, int m, void* V, long ldv, long i, long j);
+/* apply a batch of deferred Swap()s: V[:, dst[c]] <- V[:, src[c]] simultaneously; src/dst are host arrays, scratch is a
+ * device matrix with at least max(dst)+1 columns (the Impl passes its second vector buffer) */
+int chase_hip_permute_cols(chase_hip_ctx* ctx, int cplx, int m, void* V, long ldv, void* scratch, long lds,
+                           const int* src_host, const int* dst_host, int cnt);
+/* strided host <-> device matrix transfers (synchronous).  Replace Hmat_->H2D() / cublasGetMatrix
+ * (chase_gpu.hpp:536,1010-1018) */
+int chase_hip_upload_matrix(chase_hip_ctx* ctx, int cplx, int m, int n, const void* host, long ldh, void* dev, long ldd);
+int chase_hip_download_matrix(chase_hip_ctx* ctx, int cplx, int m, int n, const void* dev, long ldd, void* host,
+                              long ldh);
+/* X[row0:, :] *= s.  Replaces cuda/flipSign.cu:19-260 (s = -1) and scaleLowerBlockRows */
+int chase_hip_scale_rows(chase_hip_ctx* ctx, int cplx, int m, int n, void* X, long ldx, int row0, double s);
+/* in-place conjugate (complex only).  Replaces cuda/conjugate.cu:21-70 */
+int chase_hip_conj(chase_hip_ctx* ctx, int m, int n, void* X, long ldx);
+/* resid[j] = ||W_j - lambda_j V_j||_2 (squared != 0: sum of squares, for the distributed all-reduce).
+ * V == NULL gives plain column norms.  Replaces cuda/residuals.cu:113-296, cpu/residuals.hpp:72-79 */
+int chase_hip_resid_norms(chase_hip_ctx* ctx, int cplx, int m, int n, const void* W, long ldw, const void* V, long ldv,
+                          const double* lambda_host, double* resid_host, int squared);
+
+/* ---- Cholesky-QR building blocks (replace cublasTsyherk / cusolverDnTpotrf / cublasTtrsm, cuda/cholqr.hpp:110-132) */
+int chase_hip_herk(chase_hip_ctx* ctx, int cplx, int n, int k, const void* V, long ldv, void* A, long lda);
+int chase_hip_abs_trace(chase_hip_ctx* ctx, int cplx, int n, const void* A, long lda, double* out_host);
+/* returns 0 or LAPACK info > 0 (first non-positive pivot) */
+int chase_hip_potrf_upper(chase_hip_ctx* ctx, int cplx, int n, void* A, long lda);
+int chase_hip_trsm_right_upper(chase_hip_ctx* ctx, int cplx, int m, int n, const void* R, long ldr, void* V, long ldv);
+/* variant 1 = cholQR1, 2 = cholQR2, 3 = shiftedcholQR2 (linalg/internal/cpu/cholqr1.hpp:41-189); returns info */
+int chase_hip_cholqr(chase_hip_ctx* ctx, int cplx, int m, int n, void* V, long ldv, void* A, long lda, int variant,
+                     long m_global);
+/* Householder QR fallback: V <- first n columns of Q (cpu/cholqr1.hpp:203-210: geqrf + ungqr) */
+int chase_hip_houseqr(chase_hip_ctx* ctx, int cplx, int m, int n, void* V, long ldv);
+
+/* ---- Rayleigh-Ritz: host HEEVD of a device matrix ('V','L'), eigenvectors back on the device -------------------- */
+int chase_hip_heevd(chase_hip_ctx* ctx, int cplx, int n, void* A, long lda, double* w_host);
+/* host-only: all eigenpairs of a symmetric tridiagonal (Lanczos; lapackpp::t_stemr, cpu/lanczos.hpp:188) */
+int chase_hip_stemr_host(int n, double* d, double* e, double* w, double* Z, int ldz);
+
+/* ---- batched multi-vector level-1 kernels with device-resident scalars (Lanczos; cuda/lanczos_kernels.cu) ------- */
+/* out_dev[j] = X_j^H Y_j (complex: 2 doubles per column) */
+int chase_hip_col_dot(chase_hip_ctx* ctx, int cplx, int m, int n, const void* X, long ldx, const void* Y, long ldy,
+                      double* out_dev);
+int chase_hip_col_nrm2(chase_hip_ctx* ctx, int cplx, int m, int n, const void* X, long ldx, double* out_dev);
+/* Y_j += sgn * a[j*a_stride] * X_j; a is a device array of reals (a_is_real) or of T */
+int chase_hip_col_axpy(chase_hip_ctx* ctx, int cplx, int m, int n, const double* a_dev, int a_is_real, int a_stride,
+                       double sgn, const void* X, long ldx, void* Y, long ldy);
+/* X_j *= a[j] (or 1/a[j] when inverse != 0), a real device array */
+int chase_hip_col_scal(chase_hip_ctx* ctx, int cplx, int m, int n, const double* a_dev, int inverse, void* X, long ldx);
+
+/* ---- packed upper triangle (Gram all-reduce payload; cuda/lacpy.cu:837-1094) ------------------------------------ */
+int chase_hip_pack_upper(chase_hip_ctx* ctx, int cplx, int n, const void* A, long lda, void* P);
+int chase_hip_unpack_upper(chase_hip_ctx* ctx, int cplx, int n, const void* P, void* A, long lda, int mirror);
+
 #ifdef __cplusplus
 }
 #endif

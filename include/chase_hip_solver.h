@@ -1,0 +1,62 @@
+/* chase_hip_solver.h — C ABI of the host solver built on include/chase_hip.h.
+ *
+ * One opaque handle wraps a ChaseHip<T> Impl (chase_amd/host/chase_hip_impl.hpp), i.e. an implementation of the
+ * reference's ChaseBase<T> operator surface (algorithm/interface.hpp:46-434), plus the driver (chase::Solve,
+ * algorithm/algorithm.hpp:345-364).  The chase_hip_op_* entry points expose the virtuals one by one with the
+ * reference's argument meaning; chase_hip_solver_solve runs the whole ChASE iteration.
+ * Same status convention as chase_hip.h. */
+#ifndef CHASE_HIP_SOLVER_H
+#define CHASE_HIP_SOLVER_H
+#include <stddef.h>
+#include "chase_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct chase_hip_solver chase_hip_solver;
+
+typedef struct chase_hip_stats {
+    size_t iterations, filtered_vecs, lanczos_vecs, locked;
+    double t_all, t_init, t_lanczos, t_filter, t_qr, t_rr, t_resid; /* host wall seconds per phase */
+    double filter_ms_device;                                         /* HIP-event time between FilterPhaseStart/End */
+    double lowerb, upperb, lambda;
+} chase_hip_stats;
+
+/* H (N x N, ldh), V (N x (nev+nex), ldv) column-major; ritzv: nev+nex doubles.  cplx: 0 = double, 1 = complex double.
+ * H and V are host pointers owned by the caller (ChASECPU/ChASEGPU constructor contract, chase_cpu.hpp:73-74);
+ * h_on_device != 0 declares H a device pointer that is used in place. */
+int chase_hip_solver_create(chase_hip_solver** out, chase_hip_ctx* ctx, int cplx, size_t N, size_t nev, size_t nex,
+                            void* H, size_t ldh, void* V, size_t ldv, double* ritzv, int h_on_device);
+int chase_hip_solver_destroy(chase_hip_solver* s);
+/* keys: tol deg maxdeg degextra maxiter lanczositer numlanczos opt approx cholqr decayingrate
+ * (ChaseConfig setters, algorithm/configuration.hpp:197-462); get additionally: locked qr_variant filter_ms */
+int chase_hip_solver_set(chase_hip_solver* s, const char* key, double value);
+int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* value);
+int chase_hip_solver_solve(chase_hip_solver* s, int record_trace);
+int chase_hip_solver_stats(chase_hip_solver* s, chase_hip_stats* out);
+const double* chase_hip_solver_resid(chase_hip_solver* s); /* nev+nex residuals (host) */
+const char* chase_hip_solver_trace(chase_hip_solver* s);   /* '\n'-separated virtual-call trace of the last solve */
+int chase_hip_solver_peek_v(chase_hip_solver* s, chase_hip_ctx* ctx, void* host, size_t ldh);
+
+/* the ChaseBase virtuals */
+int chase_hip_op_start(chase_hip_solver* s);
+int chase_hip_op_end(chase_hip_solver* s);
+int chase_hip_op_initvecs(chase_hip_solver* s, int random);
+int chase_hip_op_shift(chase_hip_solver* s, double c, int isunshift);
+int chase_hip_op_hemm(chase_hip_solver* s, size_t block, const double* alpha, const double* beta, size_t offset_left,
+                      size_t offset_right);
+int chase_hip_op_qr(chase_hip_solver* s, size_t fixednev, double cond);
+int chase_hip_op_rr(chase_hip_solver* s, double* ritzv, size_t block);
+int chase_hip_op_resd(chase_hip_solver* s, double* ritzv, double* resd, size_t fixednev);
+int chase_hip_op_swap(chase_hip_solver* s, size_t i, size_t j);
+int chase_hip_op_lock(chase_hip_solver* s, size_t new_converged);
+/* numvec == 0 selects the single-vector Lanczos(m, upperb) overload */
+int chase_hip_op_lanczos(chase_hip_solver* s, size_t M, size_t numvec, double* upperb, double* ritzv, double* Tau,
+                         double* ritzV);
+int chase_hip_op_lanczos_dos(chase_hip_solver* s, size_t idx, size_t m, void* ritzVc);
+int chase_hip_op_check_symmetry(chase_hip_solver* s, int* is_sym);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,105 @@
+"""Pins the CPU oracle (oracle/chase_oracle.py) against the known-answer tests and fixtures the reference's own test
+suite holds for the hot path.  CPU only."""
+import math
+import numpy as np
+import pytest
+from conftest import read_ref_matrix
+from oracle import chase_oracle as O
+
+EPS = np.finfo(np.float64).eps
+
+
+def test_mt19937_known_answer():
+    # ISO C++ [rand.predef]: the 10000th invocation of a default-constructed mt19937 produces 4123659995
+    assert int(O.StdNormal(5489).raw(10000)[-1]) == 4123659995
+
+
+def test_normal_stream_is_chunking_invariant():
+    a = O.StdNormal(1337)
+    x = np.concatenate([a.draw(7), a.draw(4), a.draw(1), a.draw(100)])
+    y = O.StdNormal(1337).draw(112)
+    assert np.array_equal(x, y)
+    assert abs(y.mean()) < 0.3 and 0.7 < y.std() < 1.3
+
+
+def test_hemm_known_answer_49_986():
+    # tests/linalg/internal/mpi/hemm.cpp:36-119: H == 1 (10x10), V == 2, W == 3, alpha 2, beta 3, 2 of 4 columns
+    k = O.OracleCPU(np.ones((10, 10), order="F"), 2, 2)
+    k.V1[:] = 2.0
+    k.V2[:] = 3.0
+    k.HEMM(2, 2.0, 3.0, 0)          # V2 = 2*H*V1 + 3*V2 on two columns, then swap
+    assert np.all(k.V1[:, :2] == 49.0) and np.all(k.V1[:, 2:] == 3.0)
+    k.HEMM(2, 2.0, 3.0, 0)
+    assert np.all(k.V1[:, :2] == 986.0) and np.all(k.V1[:, 2:] == 2.0)
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_cholqr_reference_fixtures(cplx):
+    # tests/linalg/internal/cpu/cholqr1.cpp:31-126 (m = 100, n = 50)
+    pre = "matrix_cdouble_" if cplx else "matrix_double_"
+    V10 = read_ref_matrix(pre + "cond_10.bin", 100, 50, cplx)
+    V1e4 = read_ref_matrix(pre + "cond_1e4.bin", 100, 50, cplx)
+    Vill = read_ref_matrix(pre + "cond_ill.bin", 100, 50, cplx)
+    Q, info = O.cholQR1(V10)
+    assert info == 0 and abs(O.orthogonality(Q) - EPS) <= 15 * EPS
+    Q, info = O.cholQR1(V1e4)
+    assert info == 0 and EPS < O.orthogonality(Q) < 1.0
+    _, info = O.cholQR1(Vill)
+    assert 0 < info <= 50
+    Q, info = O.cholQR2(V1e4)
+    assert info == 0 and abs(O.orthogonality(Q) - EPS) <= 15 * EPS
+    _, info = O.cholQR2(Vill)
+    assert 0 < info <= 50
+    Q, info = O.shiftedcholQR2(Vill)
+    assert info == 0 and abs(O.orthogonality(Q) - EPS) <= 10 * EPS
+    # Householder (tests/linalg/internal/mpi/householder_qr.cpp:46-93: 25 eps)
+    assert O.orthogonality(O.houseQR(Vill)) <= 25 * EPS
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_rayleigh_ritz_known_spectrum(cplx):
+    # tests/linalg/internal/cpu/rayleighRitz.cpp:48-118: H = Q diag(0.1 (i+1)) Q^H, N = 50, n = 10
+    N, n = 50, 10
+    X = O.random_start_vectors(N, N, cplx)
+    Qf, _ = np.linalg.qr(X)
+    lam = 0.1 * (np.arange(N) + 1)
+    H = (Qf * lam[None, :]) @ Qf.conj().T
+    H = np.asfortranarray((H + H.conj().T) / 2)
+    w, V = O.rayleighRitz(H, Qf[:, :n])
+    assert np.max(np.abs(w - lam[:n])) <= 100 * EPS
+    assert np.max(O.residuals(H, w, V)) <= 1e3 * EPS
+
+
+def test_residuals_diagonal_case():
+    # tests/linalg/internal/cpu/residuals.cpp:40-80: diagonal H, unit vectors -> zero residuals
+    N = 20
+    H = np.diag(np.arange(1.0, N + 1))
+    V = np.eye(N)[:, :5]
+    assert np.max(O.residuals(H, np.arange(1.0, 6), V)) <= EPS
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_clement_solve_n256(cplx):
+    # tests/chase_serial_solve.cpp:36-190: N = 256, nev = 24, nex = 16, tol 1e-10, deg 16 -> residuals < 1e-8
+    H = O.clement(256, cplx)
+    assert np.allclose(H, H.conj().T)
+    k = O.OracleCPU(H, 24, 16)
+    k.config.deg = 16
+    st = O.solve(k)
+    assert st["iterations"] < 25
+    assert np.all(np.isfinite(k.ritzv[:24]))
+    assert np.max(k.resid[:24]) < 1e-8
+    assert np.max(O.residuals(H, k.ritzv[:24], k.V1[:, :24])) < 1e-8
+    assert np.all(np.diff(k.ritzv[:24]) >= 0)
+    # spectrum of this Clement variant: -N, -N+2, ... (measured with the reference)
+    assert np.max(np.abs(k.ritzv[:5] - (-256 + 2 * np.arange(5)))) < 1e-4
+
+
+def test_clement_solve_n1001():
+    # tests/chase_distributed_solve.cpp:209-284 shape: N = 1001, nev = 100, nex = 60
+    H = O.clement(1001, False)
+    k = O.OracleCPU(H, 100, 60)
+    st = O.solve(k)
+    assert st["iterations"] < 25
+    assert np.max(k.resid[:100]) < 1e-8
+    assert np.max(O.residuals(H, k.ritzv[:100], k.V1[:, :100])) < 1e-8
