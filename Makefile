@@ -7,10 +7,11 @@ OUT   := chase_amd/lib/libchase_hip.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -I$(HOST) -Wno-unused-result
 SRCS  := $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp) $(wildcard $(HOST)/*.cpp)
 OBJS  := $(patsubst %,build/%.o,$(SRCS))
+HDRS  := $(wildcard include/*.h) $(wildcard $(CSRC)/*.h) $(wildcard $(HOST)/*.hpp)
 
 all: $(OUT)
 
-build/%.o: %
+build/%.o: % $(HDRS)
 	@mkdir -p $(dir $@)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -171,6 +171,13 @@ class Context:
             check(lib.chase_hip_gemm_d(self.h, op, m, n, k, float(alpha), A, lda, B, ldb, float(beta), Cm, ldc),
                   "gemm_d")
 
+    def gen_clement(self, N, cplx, scale=1.0, perturb=0.0, seed=42):
+        """Whole N x N Clement-type test matrix generated in HBM (see chase_hip_gen_clement)."""
+        dH = self.empty((N, N), np.complex128 if cplx else np.float64)
+        check(lib.chase_hip_gen_clement(self.h, int(cplx), dH.ptr, N, N, N, N, N, 1, 0, 0, N, 1, 0, 0, float(scale),
+                                        float(perturb), seed), "gen_clement")
+        return dH
+
     def mfma_f64_peak(self):
         t = c_double()
         check(lib.chase_hip_mfma_f64_peak(self.h, C.byref(t)), "mfma_f64_peak")
@@ -186,6 +193,11 @@ class Context:
 _sig("chase_hip_set_lapack_lib", c_int, C.c_char_p)
 _sig("chase_hip_lapack_provider", C.c_char_p)
 _sig("chase_hip_set_host_threads", c_int, c_int)
+_sig("chase_hip_ctx_set_phase", c_int, c_void_p, c_int)
+_sig("chase_hip_fill_normal", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_long, c_long, c_long,
+     C.c_ulonglong)
+_sig("chase_hip_gen_clement", c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_int, c_long, c_int, c_int, c_int,
+     c_long, c_int, c_int, c_int, c_long, c_double, c_double, C.c_ulonglong)
 _sig("chase_hip_shift_diag", c_int, c_void_p, c_int, c_int, c_void_p, c_long, c_double)
 _sig("chase_hip_shift_list", c_int, c_void_p, c_int, c_void_p, c_long, c_void_p, c_void_p, c_int, c_double)
 _sig("chase_hip_lacpy", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long)

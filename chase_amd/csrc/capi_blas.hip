@@ -43,7 +43,7 @@ int gemm(chase_hip_ctx* c, int cplx, char op, int m, int n, int k, double ar, do
     RCCHK(c->ensure_ws(WS_DEFAULT));
     const double alpha[2] = {ar, ai}, beta[2] = {br, bi};
     int e = gemm_f64(c->stream, cplx != 0, op, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, (double*)c->ws,
-                     c->ws_bytes, c->num_cu);
+                     c->ws_bytes, c->num_cu, c->phase);
     if (e) return hip_fail((hipError_t)e, "gemm launch");
     return 0;
 }
@@ -61,6 +61,39 @@ int chase_hip_set_host_threads(int n)
 {
     lapack_bind(nullptr);
     lapack_set_threads(n);
+    return 0;
+}
+
+int chase_hip_ctx_set_phase(chase_hip_ctx* c, int phase)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "set_phase: NULL ctx");
+    c->phase = phase;
+    return 0;
+}
+
+/* X (m x n local window whose first element is global (grow0, gcol0) of a matrix with gld global rows) ~ N(0,1) */
+int chase_hip_fill_normal(chase_hip_ctx* c, int cplx, int m, int n, void* X, long ldx, long grow0, long gcol0, long gld,
+                          unsigned long long seed)
+{
+    if (!c || !X) return set_error(CHASE_HIP_EINVAL, "fill_normal: NULL argument");
+    if (m < 0 || n < 0 || ldx < m) return set_error(CHASE_HIP_EINVAL, "fill_normal: bad shape");
+    KCHK(fill_normal(c->stream, cplx != 0, (double*)X, ldx, m, n, grow0, gcol0, gld, seed), "fill_normal");
+    return 0;
+}
+
+/* local shard (mloc x nloc) of the N x N Clement-type test matrix.  Rows: global = roff + ((l / mb) * pr + pi) * mb +
+ * l % mb; columns likewise with (nb, pc, pj, coff).  Whole matrix on one GPU: mb = nb = N, pr = pc = 1, rest 0.
+ * H = scale * (Clement + perturb * Hermitian N(0,1)); perturb = 0 gives the unperturbed tridiagonal matrix. */
+int chase_hip_gen_clement(chase_hip_ctx* c, int cplx, void* H, long ldh, int mloc, int nloc, long N, int mb, int pr,
+                          int pi, long roff, int nb, int pc, int pj, long coff, double scale, double perturb,
+                          unsigned long long seed)
+{
+    if (!c || !H) return set_error(CHASE_HIP_EINVAL, "gen_clement: NULL argument");
+    if (mloc < 0 || nloc < 0 || ldh < mloc || mb <= 0 || nb <= 0 || pr <= 0 || pc <= 0)
+        return set_error(CHASE_HIP_EINVAL, "gen_clement: bad shape");
+    KCHK(gen_clement(c->stream, cplx != 0, (double*)H, ldh, mloc, nloc, N, mb, pr, pi, roff, nb, pc, pj, coff, scale,
+                     perturb, seed),
+         "gen_clement");
     return 0;
 }
 

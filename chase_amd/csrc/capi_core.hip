@@ -192,7 +192,7 @@ int chase_hip_gemm_d(chase_hip_ctx* c, char opA, int m, int n, int k, double alp
     rc = c->ensure_ws((size_t)64 << 20);
     if (rc) return rc;
     int e = gemm_f64(c->stream, false, opA, m, n, k, &alpha, A, lda, B, ldb, &beta, C, ldc, (double*)c->ws,
-                     c->ws_bytes, c->num_cu);
+                     c->ws_bytes, c->num_cu, c->phase);
     if (e) return hip_fail((hipError_t)e, "gemm_d launch");
     return 0;
 }
@@ -207,7 +207,7 @@ int chase_hip_gemm_z(chase_hip_ctx* c, char opA, int m, int n, int k, const doub
     rc = c->ensure_ws((size_t)64 << 20);
     if (rc) return rc;
     int e = gemm_f64(c->stream, true, opA, m, n, k, alpha, (const double*)A, lda, (const double*)B, ldb, beta,
-                     (double*)C, ldc, (double*)c->ws, c->ws_bytes, c->num_cu);
+                     (double*)C, ldc, (double*)c->ws, c->ws_bytes, c->num_cu, c->phase);
     if (e) return hip_fail((hipError_t)e, "gemm_z launch");
     return 0;
 }

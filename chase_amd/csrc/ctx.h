@@ -12,6 +12,7 @@ struct chase_hip_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int phase = 0;               // 1 between FilterPhaseStart/End: selects the filter-tagged GEMM symbol
     void* ws = nullptr;          // split-K slabs, grown on demand
     size_t ws_bytes = 0;
     enum { BUF_TINV = 0, BUF_PANEL, BUF_SCAL, BUF_LAMBDA, NBUF };

@@ -76,7 +76,9 @@ struct GemmArgs {
     long slab_stride;                                // elements of T between split-K slabs (0 if splitk == 1)
 };
 
-template <bool CPLX, bool OPA_C>
+// TAG only changes the symbol name: TAG = 1 is the instantiation launched between FilterPhaseStart/End, so that
+// rocprofv3 --kernel-trace --stats reports the Chebyshev-filter HEMM separately from the QR / RR / residual products.
+template <bool CPLX, bool OPA_C, int TAG>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
 {
     using C_ = Cfg<CPLX, OPA_C>;
@@ -381,7 +383,7 @@ __global__ void splitk_reduce_kernel(const double* __restrict__ slabs, long slab
     }
 }
 
-template <bool CPLX, bool OPA_C>
+template <bool CPLX, bool OPA_C, int TAG>
 static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha, const double* A, long lda,
                        const double* B, long ldb, const double* beta, double* C, long ldc,
                        double* ws, size_t ws_bytes, int num_cu)
@@ -416,10 +418,10 @@ static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha,
     const size_t lds_bytes = 2 * C_::STAGE_UNITS * sizeof(d2_t);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C>), dim3(grid), dim3(256), lds_bytes, st, a);
+    hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG>), dim3(grid), dim3(256), lds_bytes, st, a);
     if (splitk > 1) {
         const long total = (long)m * n;
         unsigned rb = (unsigned)((total + 255) / 256); if (rb > 4096) rb = 4096;
@@ -430,15 +432,16 @@ static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha,
 }
 
 int gemm_f64(hipStream_t st, bool cplx, char opA, int m, int n, int k, const double* alpha, const double* A, long lda,
-             const double* B, long ldb, const double* beta, double* C, long ldc, double* ws, size_t ws_bytes, int num_cu)
+             const double* B, long ldb, const double* beta, double* C, long ldc, double* ws, size_t ws_bytes, int num_cu,
+             int tag)
 {
     const bool opc = (opA == 'C' || opA == 'c' || opA == 'T' || opA == 't');
-    if (!cplx) {
-        return opc ? launch_gemm<false, true>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu)
-                   : launch_gemm<false, false>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu);
-    }
-    return opc ? launch_gemm<true, true>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu)
-               : launch_gemm<true, false>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu);
+#define CHASE_GEMM_DISPATCH(CP, OC)                                                                                    \
+    (tag == 1 ? launch_gemm<CP, OC, 1>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu)         \
+              : launch_gemm<CP, OC, 0>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu))
+    if (!cplx) return opc ? CHASE_GEMM_DISPATCH(false, true) : CHASE_GEMM_DISPATCH(false, false);
+    return opc ? CHASE_GEMM_DISPATCH(true, true) : CHASE_GEMM_DISPATCH(true, false);
+#undef CHASE_GEMM_DISPATCH
 }
 
 // ---- register-resident MFMA peak probe ("to be confirmed by a register-resident MFMA micro-benchmark")

@@ -10,7 +10,7 @@ namespace chase_hip {
 // ws/ws_bytes: optional device workspace for deterministic split-K.
 int gemm_f64(hipStream_t st, bool cplx, char opA, int m, int n, int k, const double* alpha, const double* A, long lda,
              const double* B, long ldb, const double* beta, double* C, long ldc, double* ws, size_t ws_bytes,
-             int num_cu);
+             int num_cu, int tag = 0);
 
 int mfma_f64_peak(hipStream_t st, double* out, int blocks, int iters);
 int stream_copy(hipStream_t st, void* dst, const void* src, size_t bytes);
@@ -37,6 +37,12 @@ int conj_inplace(hipStream_t st, double* X, long ldx_d, int m, int ncols);
 int pack_upper(hipStream_t st, const double* A, long lda, int n, int ept, double* P);
 int unpack_upper(hipStream_t st, double* P, int n, int ept, double* A, long lda);
 int mirror_upper(hipStream_t st, double* A, long lda, int n, int ept);
+
+// ---- generators (gen_kernels.hip) ----
+int fill_normal(hipStream_t st, bool cplx, double* X, long ldx, int m, int n, long grow0, long gcol0, long gld,
+                unsigned long long seed);
+int gen_clement(hipStream_t st, bool cplx, double* H, long ldh, int mloc, int nloc, long N, int mb, int pr, int pi,
+                long roff, int nb, int pc, int pj, long coff, double scale, double perturb, unsigned long long seed);
 
 // ---- factorisation cores (factor_kernels.hip) ----
 int potf2_trtri(hipStream_t st, bool cplx, double* A, long lda, int nb, int joff, double* Tinv, int* info_dev);

@@ -131,13 +131,18 @@ public:
     // reference: chase_cpu.hpp:296-327 (mt19937(1337), column-major fill) + chase_gpu.hpp:520-537 (copy, H2D)
     void initVecs(bool random) override
     {
-        if (random) {
-            std::mt19937 gen(1337.0);
-            std::normal_distribution<> d;
-            for (std::size_t j = 0; j < nevex_; ++j)
-                for (std::size_t i = 0; i < N_; ++i) V1_[i + j * ldv_] = rnd(d, gen);
+        if (random && device_rng_) {
+            // ChASEGPU behaviour: generate on the device (chase_gpu.hpp:520-525), no host staging of N x nevex
+            hip_ok(chase_hip_fill_normal(ctx_, CP, (int)N_, (int)nevex_, dV1_, (long)N_, 0, 0, (long)N_, 1337ull), "fill_normal");
+        } else {
+            if (random) {
+                std::mt19937 gen(1337.0);
+                std::normal_distribution<> d;
+                for (std::size_t j = 0; j < nevex_; ++j)
+                    for (std::size_t i = 0; i < N_; ++i) V1_[i + j * ldv_] = rnd(d, gen);
+            }
+            hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)N_, (int)nevex_, V1_, (long)ldv_, dV1_, (long)N_), "upload V");
         }
-        hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)N_, (int)nevex_, V1_, (long)ldv_, dV1_, (long)N_), "upload V");
         hip_ok(chase_hip_lacpy(ctx_, CP, (int)N_, (int)nevex_, dV1_, (long)N_, dV2_, (long)N_), "lacpy");
         reset_perm();
         upload_H();
@@ -151,13 +156,24 @@ public:
     }
 
     // ---- filter --------------------------------------------------------------------------------------------------
-    void FilterPhaseStart() override { hip_ok(chase_hip_timer_start(ctx_), "timer"); }
+    void FilterPhaseStart() override
+    {
+        flush_swaps();                                        // keep the permutation launches out of the timed phase
+        chase_hip_ctx_set_phase(ctx_, 1);
+        hip_ok(chase_hip_timer_start(ctx_), "timer");
+    }
     void FilterPhaseEnd() override
     {
         float ms = 0;
         hip_ok(chase_hip_timer_stop(ctx_, &ms), "timer");     // synchronises the stream
+        chase_hip_ctx_set_phase(ctx_, 0);
         filter_ms_ += ms;
     }
+    // true: initVecs(random) draws N(0,1) on the device like ChASEGPU; false (default): mt19937(1337) on the host,
+    // bitwise the start vectors of ChASECPU (used by the parity tests)
+    void set_device_rng(bool f) { device_rng_ = f; }
+    void reset_counters() { filter_ms_ = 0; hemm_calls_ = 0; }
+    std::size_t hemm_calls() const { return hemm_calls_; }
 
     void Shift(T c, bool = false) override
     {
@@ -172,6 +188,7 @@ public:
         if (ncols != 0) {
             const std::size_t c0 = locked_ + offset_left;
             gemm('N', N_, ncols, N_, alpha, dH_, ldd_h_, dV1_ + c0 * N_, N_, beta, dV2_ + c0 * N_, N_);
+            ++hemm_calls_;
         }
         std::swap(dV1_, dV2_);
     }
@@ -390,6 +407,8 @@ private:
     std::size_t ldd_h_ = 0;
     std::vector<void*> owned_;
     double filter_ms_ = 0;
+    std::size_t hemm_calls_ = 0;
+    bool device_rng_ = false;
     int last_qr_variant_ = 0;
 };
 

@@ -90,6 +90,8 @@ int chase_hip_solver_set(chase_hip_solver* s, const char* key, double v)
         else if (name == "approx") c.SetApprox(v != 0);
         else if (name == "cholqr") c.SetCholQR(v != 0);
         else if (name == "decayingrate") c.SetDecayingRate((float)v);
+        else if (name == "device_rng") k.set_device_rng(v != 0);
+        else if (name == "reset_counters") k.reset_counters();
         else rc = chase_hip::set_error(CHASE_HIP_EINVAL, "solver_set: unknown key");
     });
     return rc;
@@ -116,6 +118,7 @@ int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* out)
         else if (name == "locked") *out = (double)k.locked();
         else if (name == "qr_variant") *out = (double)k.last_qr_variant();
         else if (name == "filter_ms") *out = k.filter_ms();
+        else if (name == "hemm_calls") *out = (double)k.hemm_calls();
         else rc = chase_hip::set_error(CHASE_HIP_EINVAL, "solver_get: unknown key");
     });
     return rc;

@@ -70,6 +70,20 @@ int chase_hip_mfma_f64_peak(chase_hip_ctx* ctx, double* tflops);
 /* streaming-copy probe: achieved HBM GB/s for a bytes-sized device-to-device float4 copy */
 int chase_hip_hbm_copy_peak(chase_hip_ctx* ctx, size_t bytes, double* gbps);
 
+/* phase 1 = inside FilterPhaseStart/End: GEMMs are launched through the filter-tagged kernel symbol so that rocprofv3
+ * reports the Chebyshev-filter HEMM separately (numerics identical); 0 = everything else */
+int chase_hip_ctx_set_phase(chase_hip_ctx* ctx, int phase);
+
+/* ---- on-device input generators (global-index addressed, shard-safe) ------------------------------------------ */
+/* N(0,1) fill (Philox4x32-10 + Box-Muller).  Replaces cuda/random_normal_distribution.cu:21-95 (initVecs on GPU) */
+int chase_hip_fill_normal(chase_hip_ctx* ctx, int cplx, int m, int n, void* X, long ldx, long grow0, long gcol0,
+                          long gld, unsigned long long seed);
+/* Clement-type test matrix of the reference's solve tests (tests/chase_serial_solve.cpp:52-90), any 2D shard:
+ * H = scale * (Clement + perturb * G), G dense Hermitian N(0,1) on the entries the reference perturbs */
+int chase_hip_gen_clement(chase_hip_ctx* ctx, int cplx, void* H, long ldh, int mloc, int nloc, long N, int mb, int pr,
+                          int pi, long roff, int nb, int pc, int pj, long coff, double scale, double perturb,
+                          unsigned long long seed);
+
 /* ---- host LAPACK provider (HEEVD / STEMR stay on the host per the north star) --------------------------------- */
 int chase_hip_set_lapack_lib(const char* path);   /* optional explicit LP64 LAPACK shared library */
 const char* chase_hip_lapack_provider(void);      /* path of the bound provider ("" if none) */
