@@ -4,7 +4,7 @@ ARCH  ?= gfx950
 CSRC  := chase_amd/csrc
 HOST  := chase_amd/host
 OUT   := chase_amd/lib/libchase_hip.so
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -I$(HOST) -Wno-unused-result
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I/opt/rocm/include -I$(CSRC) -I$(HOST) -Wno-unused-result
 SRCS  := $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp) $(wildcard $(HOST)/*.cpp)
 OBJS  := $(patsubst %,build/%.o,$(SRCS))
 HDRS  := $(wildcard include/*.h) $(wildcard $(CSRC)/*.h) $(wildcard $(HOST)/*.hpp)
@@ -17,7 +17,7 @@ build/%.o: % $(HDRS)
 
 $(OUT): $(OBJS)
 	@mkdir -p $(dir $@)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -ldl -lpthread
 
 clean:
 	rm -rf build $(OUT)

@@ -81,6 +81,26 @@ int chase_hip_fill_normal(chase_hip_ctx* c, int cplx, int m, int n, void* X, lon
     return 0;
 }
 
+/* same, rows of the local window are the block-cyclic rows (mb, pr, pi) of the global matrix */
+int chase_hip_fill_normal_bc(chase_hip_ctx* c, int cplx, int m, int n, void* X, long ldx, long gld, int mb, int pr,
+                             int pi, unsigned long long seed)
+{
+    if (!c || !X) return set_error(CHASE_HIP_EINVAL, "fill_normal_bc: NULL argument");
+    if (m < 0 || n < 0 || ldx < m || mb <= 0 || pr <= 0) return set_error(CHASE_HIP_EINVAL, "fill_normal_bc: bad shape");
+    KCHK(fill_normal(c->stream, cplx != 0, (double*)X, ldx, m, n, 0, 0, gld, seed, mb, pr, pi), "fill_normal_bc");
+    return 0;
+}
+
+/* rows by index list: scatter == 0: out[p,:] = in[idx[p],:];  scatter != 0: out[idx[p],:] = in[p,:]  (idx on device) */
+int chase_hip_rows_indexed(chase_hip_ctx* c, int cplx, const void* in, long ld_in, void* out, long ld_out,
+                           const int* idx_dev, int np, int ncols, int scatter)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "rows_indexed: NULL ctx");
+    KCHK(rows_indexed(c->stream, cplx != 0, (const double*)in, ld_in, (double*)out, ld_out, idx_dev, np, ncols, scatter),
+         "rows_indexed");
+    return 0;
+}
+
 /* local shard (mloc x nloc) of the N x N Clement-type test matrix.  Rows: global = roff + ((l / mb) * pr + pi) * mb +
  * l % mb; columns likewise with (nb, pc, pj, coff).  Whole matrix on one GPU: mb = nb = N, pr = pc = 1, rest 0.
  * H = scale * (Clement + perturb * Hermitian N(0,1)); perturb = 0 gives the unperturbed tridiagonal matrix. */
@@ -352,6 +372,13 @@ int chase_hip_heevd(chase_hip_ctx* c, int cplx, int n, void* A, long lda, double
     return 0;
 }
 
+/* host-only twin of chase_hip_heevd (exercises the bound LAPACK provider without a GPU) */
+int chase_hip_heevd_host(int cplx, int n, void* A_host, long lda, double* w_host)
+{
+    if (!A_host || !w_host) return set_error(CHASE_HIP_EINVAL, "heevd_host: NULL argument");
+    return host_heevd(cplx != 0, n, (double*)A_host, (int)lda, w_host);
+}
+
 /* host-only helper: all eigenpairs of a symmetric tridiagonal matrix (reference lapackpp::t_stemr, cpu/lanczos.hpp:188) */
 int chase_hip_stemr_host(int n, double* d, double* e, double* w, double* Z, int ldz)
 {
@@ -372,6 +399,20 @@ int chase_hip_col_nrm2(chase_hip_ctx* c, int cplx, int m, int n, const void* X, 
     if (!c) return set_error(CHASE_HIP_EINVAL, "col_nrm2: NULL ctx");
     const int e = ept_of(cplx);
     KCHK(resid_norms(c->stream, (const double*)X, ldx * e, nullptr, 0, nullptr, (long)m * e, n, out_dev, 1), "col_nrm2");
+    return 0;
+}
+/* out_dev[j] = sum_i |X[i,j]|^2 (no sqrt: partial sums for a distributed norm) */
+int chase_hip_col_sumsq(chase_hip_ctx* c, int cplx, int m, int n, const void* X, long ldx, double* out_dev)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "col_sumsq: NULL ctx");
+    const int e = ept_of(cplx);
+    KCHK(resid_norms(c->stream, (const double*)X, ldx * e, nullptr, 0, nullptr, (long)m * e, n, out_dev, 0), "col_sumsq");
+    return 0;
+}
+int chase_hip_sqrt_inplace(chase_hip_ctx* c, double* x_dev, int n)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "sqrt_inplace: NULL ctx");
+    KCHK(sqrt_inplace(c->stream, x_dev, n), "sqrt_inplace");
     return 0;
 }
 int chase_hip_col_axpy(chase_hip_ctx* c, int cplx, int m, int n, const double* a_dev, int a_is_real, int a_stride,

@@ -42,14 +42,17 @@ __device__ __forceinline__ void normal_pair(unsigned long long ctr, unsigned lon
     z0 = r * c; z1 = r * s;
 }
 
-// X[i, j] ~ N(0,1) (complex: re and im independent N(0,1)); element identity = global (grow0 + i, gcol0 + j)
+// X[i, j] ~ N(0,1) (complex: re and im independent N(0,1)); element identity = global (row(i), gcol0 + j) with
+// row(i) = grow0 + i (mb == 0: contiguous window) or grow0 + ((i / mb) * pr + pi) * mb + i % mb (block-cyclic rows)
 template <bool CPLX>
 __global__ __launch_bounds__(256) void fill_normal_kernel(double* __restrict__ X, long ldx, int m, int n, long grow0,
-                                                          long gcol0, long gld, unsigned long long seed)
+                                                          long gcol0, long gld, unsigned long long seed, int mb, int pr,
+                                                          int pi)
 {
     for (int j = blockIdx.y; j < n; j += gridDim.y) {
         for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
-            const unsigned long long g = (unsigned long long)(gcol0 + j) * (unsigned long long)gld + (unsigned long long)(grow0 + i);
+            const long gr = (mb > 0) ? grow0 + ((long)(i / mb) * pr + pi) * mb + i % mb : grow0 + i;
+            const unsigned long long g = (unsigned long long)(gcol0 + j) * (unsigned long long)gld + (unsigned long long)gr;
             double z0, z1;
             if constexpr (CPLX) {
                 normal_pair(g, seed, z0, z1);
@@ -103,11 +106,11 @@ static inline dim3 grid_for(int m, int n)
 }
 
 int fill_normal(hipStream_t st, bool cplx, double* X, long ldx, int m, int n, long grow0, long gcol0, long gld,
-                unsigned long long seed)
+                unsigned long long seed, int mb, int pr, int pi)
 {
     if (m <= 0 || n <= 0) return 0;
-    if (cplx) hipLaunchKernelGGL(fill_normal_kernel<true>, grid_for(m, n), dim3(256), 0, st, X, ldx, m, n, grow0, gcol0, gld, seed);
-    else      hipLaunchKernelGGL(fill_normal_kernel<false>, grid_for(m, n), dim3(256), 0, st, X, ldx, m, n, grow0, gcol0, gld, seed);
+    if (cplx) hipLaunchKernelGGL(fill_normal_kernel<true>, grid_for(m, n), dim3(256), 0, st, X, ldx, m, n, grow0, gcol0, gld, seed, mb, pr, pi);
+    else      hipLaunchKernelGGL(fill_normal_kernel<false>, grid_for(m, n), dim3(256), 0, st, X, ldx, m, n, grow0, gcol0, gld, seed, mb, pr, pi);
     return (int)hipGetLastError();
 }
 

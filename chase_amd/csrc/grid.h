@@ -1,0 +1,23 @@
+// grid.h — the process grid behind chase_hip_grid* (include/chase_hip_grid.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <vector>
+#include "../../include/chase_hip_grid.h"
+#include "ctx.h"
+
+struct chase_hip_grid {
+    chase_hip_ctx* ctx = nullptr;
+    int nprow = 1, npcol = 1, rank = 0, myrow = 0, mycol = 0;
+    bool use_rccl = false;
+    ncclComm_t comm[2] = {nullptr, nullptr};          // [ROW], [COL]
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_compute = nullptr, ev_comm = nullptr;
+    chase_hip_host_allreduce_fn h_allreduce = nullptr;
+    chase_hip_host_bcast_fn h_bcast = nullptr;
+    void* h_user = nullptr;
+    double* scal_dev = nullptr;                        // one double for agree_max
+    std::vector<hipEvent_t> slots;                     // per-panel 'all-reduce done' events (pipelined HEMM)
+    int group_size(int g) const { return g == CHASE_HIP_ROW ? npcol : nprow; }
+    int group_rank(int g) const { return g == CHASE_HIP_ROW ? mycol : myrow; }
+};

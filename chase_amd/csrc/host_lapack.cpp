@@ -57,6 +57,15 @@ static bool try_lib(const char* path)
     if (!g_set_threads) g_set_threads = (set_threads_t)dlsym(h, "openblas_set_num_threads");
     if (!g_set_threads) g_set_threads = (set_threads_t)dlsym(h, "MKL_Set_Num_Threads");
     g_provider = path;
+    // The projected eigenproblems are small (n <= a few thousand): OpenBLAS/MKL with one thread per core of a
+    // 2 x 64-core host is 4x SLOWER than 16 threads (measured on the MI355X box: zheevd n=640 215 ms vs 55 ms,
+    // n=2560 4.1 s vs 1.0 s).  Override with CHASE_HIP_HOST_THREADS.
+    // MKL is private to this library -> default 16 threads.  A bundled OpenBLAS may be the very instance numpy/scipy use:
+    // changing its thread count behind their back crashed scipy's trsm in testing, so it is only touched on request.
+    const bool is_mkl = strstr(path, "mkl") != nullptr;
+    int nt = is_mkl ? 16 : 0;
+    if (const char* e = getenv("CHASE_HIP_HOST_THREADS")) nt = atoi(e);
+    if (g_set_threads && nt > 0) g_set_threads(nt);
     return true;
 }
 
@@ -77,6 +86,12 @@ int lapack_bind(const char* hint)
     if (g_handle) return 0;
     if (try_lib(getenv("CHASE_HIP_LAPACK_LIB"))) return 0;
     if (try_lib(hint)) return 0;
+    // 1) MKL's single dynamic library: a PRIVATE provider (numpy/scipy in the same process use their own OpenBLAS), so
+    //    its thread count can be tuned without side effects.  LP64 interface, GNU threading layer (libgomp).
+    setenv("MKL_INTERFACE_LAYER", "GNU,LP64", 0);
+    setenv("MKL_THREADING_LAYER", "GNU", 0);
+    if (try_lib("/opt/conda/lib/libmkl_rt.so") || try_lib("libmkl_rt.so.2") || try_lib("libmkl_rt.so")) return 0;
+    // 2) an OpenBLAS that Python packages bundle (shared with numpy/scipy when they are loaded: never retuned here)
     const char* pats[] = {
         "/usr/local/lib/python3*/dist-packages/scipy.libs/libscipy_openblas-*.so",
         "/usr/lib/python3*/dist-packages/scipy.libs/libscipy_openblas-*.so",
@@ -86,10 +101,6 @@ int lapack_bind(const char* hint)
     };
     for (const char* p : pats)
         if (try_glob(p)) return 0;
-    // MKL single dynamic library: LP64 + GNU threading so that it coexists with libgomp users in the process
-    setenv("MKL_INTERFACE_LAYER", "LP64", 0);
-    setenv("MKL_THREADING_LAYER", "GNU", 0);
-    if (try_lib("/opt/conda/lib/libmkl_rt.so") || try_lib("libmkl_rt.so")) return 0;
     return set_error(CHASE_HIP_ELAPACK,
                      "no host LAPACK provider found (set CHASE_HIP_LAPACK_LIB to an LP64 LAPACK shared library)");
 }

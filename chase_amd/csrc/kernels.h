@@ -22,6 +22,8 @@ int shift_diag_dev(hipStream_t st, double* A, long ld, int n, int ept, const dou
 int abs_trace(hipStream_t st, const double* A, long ld, int n, int ept, double* out_dev);
 int copy2d(hipStream_t st, const double* src, long ld_src_d, double* dst, long ld_dst_d, long md, int ncols);
 int swap_cols(hipStream_t st, double* a, double* b, long md);
+int rows_indexed(hipStream_t st, bool cplx, const double* in, long ld_in, double* out, long ld_out, const int* idx_dev,
+                 int np, int ncols, int scatter);
 int copy_cols_indexed(hipStream_t st, const double* src, long ld_src_d, double* dst, long ld_dst_d, long md,
                       const int* src_idx_dev, const int* dst_idx_dev, int cnt);
 int resid_norms(hipStream_t st, const double* W, long ldw_d, const double* V, long ldv_d, const double* lambda_dev,
@@ -40,7 +42,7 @@ int mirror_upper(hipStream_t st, double* A, long lda, int n, int ept);
 
 // ---- generators (gen_kernels.hip) ----
 int fill_normal(hipStream_t st, bool cplx, double* X, long ldx, int m, int n, long grow0, long gcol0, long gld,
-                unsigned long long seed);
+                unsigned long long seed, int mb = 0, int pr = 1, int pi = 0);
 int gen_clement(hipStream_t st, bool cplx, double* H, long ldh, int mloc, int nloc, long N, int mb, int pr, int pi,
                 long roff, int nb, int pc, int pj, long coff, double scale, double perturb, unsigned long long seed);
 

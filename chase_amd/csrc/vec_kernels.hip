@@ -296,6 +296,24 @@ __global__ __launch_bounds__(256) void copy_cols_indexed_kernel(const double* __
     }
 }
 
+// row gather / scatter by index list (redistribution between the column-type and row-type multivector layouts):
+//   scatter == 0:  out[p, c] = in[idx[p], c]        scatter != 0:  out[idx[p], c] = in[p, c]        p < np, c < ncols
+template <int EPT>
+__global__ __launch_bounds__(256) void rows_indexed_kernel(const double* __restrict__ in, long ld_in,
+                                                           double* __restrict__ out, long ld_out,
+                                                           const int* __restrict__ idx, int np, int ncols, int scatter)
+{
+    for (int c = blockIdx.y; c < ncols; c += gridDim.y) {
+        for (int p = blockIdx.x * 256 + threadIdx.x; p < np; p += gridDim.x * 256) {
+            const long r = idx[p];
+            const double* s = in + ((long)c * ld_in + (scatter ? p : r)) * EPT;
+            double* d = out + ((long)c * ld_out + (scatter ? r : p)) * EPT;
+            d[0] = s[0];
+            if (EPT == 2) d[1] = s[1];
+        }
+    }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------------------------
 static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
 static inline dim3 grid2(long md, int ncols)
@@ -342,6 +360,15 @@ int copy_cols_indexed(hipStream_t st, const double* src, long ld_src_d, double* 
     if (cnt <= 0 || md <= 0) return 0;
     hipLaunchKernelGGL(copy_cols_indexed_kernel, grid2(md, cnt), dim3(256), 0, st, src, ld_src_d, dst, ld_dst_d, md,
                        src_idx_dev, dst_idx_dev, cnt);
+    return (int)hipGetLastError();
+}
+int rows_indexed(hipStream_t st, bool cplx, const double* in, long ld_in, double* out, long ld_out, const int* idx_dev,
+                 int np, int ncols, int scatter)
+{
+    if (np <= 0 || ncols <= 0) return 0;
+    const dim3 g = grid2(np, ncols);
+    if (cplx) hipLaunchKernelGGL(rows_indexed_kernel<2>, g, dim3(256), 0, st, in, ld_in, out, ld_out, idx_dev, np, ncols, scatter);
+    else      hipLaunchKernelGGL(rows_indexed_kernel<1>, g, dim3(256), 0, st, in, ld_in, out, ld_out, idx_dev, np, ncols, scatter);
     return (int)hipGetLastError();
 }
 int swap_cols(hipStream_t st, double* a, double* b, long md)

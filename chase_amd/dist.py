@@ -1,0 +1,244 @@
+"""Multi-process plumbing for the distributed Impl (one process per GPU): torch.distributed is used ONLY to bootstrap
+(exchange RCCL unique ids, barriers, max-over-ranks timing) and, in tests, as the gloo back end of the host-callback
+transport that lets several ranks share one GPU.  The data path itself is C++/HIP/RCCL (chase_amd/csrc/grid.hip)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .capi import (lib, check, Context, DeviceArray, Stats, _sig, _z2, c_int, c_long, c_size_t, c_double, c_void_p, P)
+
+_sig("chase_hip_rccl_unique_id", c_int, C.c_char_p)
+_sig("chase_hip_grid_create_rccl", c_int, P(c_void_p), c_void_p, c_int, c_int, c_int, C.c_char_p, C.c_char_p)
+AR_FN = C.CFUNCTYPE(c_int, c_void_p, c_int, P(c_double), c_size_t)
+BC_FN = C.CFUNCTYPE(c_int, c_void_p, c_int, P(c_double), c_size_t, c_int)
+_sig("chase_hip_grid_create_host", c_int, P(c_void_p), c_void_p, c_int, c_int, c_int, AR_FN, BC_FN, c_void_p)
+_sig("chase_hip_grid_destroy", c_int, c_void_p)
+_sig("chase_hip_grid_info", c_int, c_void_p, P(c_int), P(c_int), P(c_int), P(c_int))
+_sig("chase_hip_grid_allreduce", c_int, c_void_p, c_int, c_void_p, c_size_t, c_int)
+_sig("chase_hip_grid_bcast", c_int, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int)
+_sig("chase_hip_grid_wait", c_int, c_void_p)
+_sig("chase_hip_grid_agree_max", c_int, c_void_p, P(c_int))
+for _n in ("chase_hip_block_len",):
+    _sig(_n, c_long, c_long, c_int)
+_sig("chase_hip_numroc", c_long, c_long, c_long, c_int, c_int)
+_sig("chase_hip_owner", c_int, c_long, c_long, c_int)
+_sig("chase_hip_local_index", c_long, c_long, c_long, c_int)
+_sig("chase_hip_global_index", c_long, c_long, c_long, c_int, c_int)
+_sig("chase_hip_psolver_create", c_int, P(c_void_p), c_void_p, c_void_p, c_int, c_size_t, c_size_t, c_size_t, c_size_t,
+     c_size_t, c_void_p, c_size_t, c_void_p)
+_sig("chase_hip_psolver_local_shape", c_int, c_void_p, P(c_size_t), P(c_size_t))
+_sig("chase_hip_psolver_upload_v", c_int, c_void_p, c_void_p, c_size_t)
+_sig("chase_hip_psolver_download_v", c_int, c_void_p, c_void_p, c_size_t)
+_sig("chase_hip_psolver_set_pipeline", c_int, c_void_p, c_int)
+
+ROW, COL = 0, 1
+
+
+def grid_shape(nranks):
+    """The reference requires row_dim >= col_dim (grid/mpiGrid2D.hpp:209-211): 1 -> 1x1, 2 -> 2x1, 4 -> 2x2, 8 -> 4x2."""
+    c = int(np.floor(np.sqrt(nranks)))
+    while nranks % c:
+        c -= 1
+    return nranks // c, c
+
+
+def coords_of(rank, nprow):
+    return rank % nprow, rank // nprow          # column-major grid ordering
+
+
+class Layout:
+    """1D block-cyclic index map (block layout = block size equal to the block length)."""
+
+    def __init__(self, N, nb, p):
+        self.N, self.p = N, p
+        self.nb = nb if nb else lib.chase_hip_block_len(N, p)
+
+    def count(self, q): return lib.chase_hip_numroc(self.N, self.nb, q, self.p)
+    def owner(self, g): return lib.chase_hip_owner(g, self.nb, self.p)
+    def local(self, g): return lib.chase_hip_local_index(g, self.nb, self.p)
+
+    def globals_of(self, q):
+        n = self.count(q)
+        l = np.arange(n)
+        return ((l // self.nb) * self.p + q) * self.nb + l % self.nb
+
+
+class Grid:
+    def __init__(self, ctx, nprow, npcol, rank, transport="rccl", pg=None):
+        """pg: dict {"world": group, "row": group, "col": group} of torch.distributed groups (host transport /
+        bootstrap)."""
+        import torch.distributed as dist
+        self.ctx, self.nprow, self.npcol, self.rank = ctx, nprow, npcol, rank
+        self.myrow, self.mycol = coords_of(rank, nprow)
+        self.transport = transport
+        h = c_void_p()
+        if transport == "rccl":
+            my_id = C.create_string_buffer(128)
+            check(lib.chase_hip_rccl_unique_id(my_id), "rccl_unique_id")
+            ids = [None] * (nprow * npcol)
+            if nprow * npcol > 1:
+                dist.all_gather_object(ids, bytes(my_id.raw))
+            else:
+                ids = [bytes(my_id.raw)]
+            row_leader = self.myrow                         # (myrow, 0)
+            col_leader = self.mycol * nprow                 # (0, mycol): a different rank than the row leader's id use
+            # a rank may lead both its row and its column group (rank 0): use distinct ids -> generate a second one
+            my_id2 = C.create_string_buffer(128)
+            check(lib.chase_hip_rccl_unique_id(my_id2), "rccl_unique_id")
+            ids2 = [None] * (nprow * npcol)
+            if nprow * npcol > 1:
+                dist.all_gather_object(ids2, bytes(my_id2.raw))
+            else:
+                ids2 = [bytes(my_id2.raw)]
+            check(lib.chase_hip_grid_create_rccl(C.byref(h), ctx.h, nprow, npcol, rank, ids[row_leader],
+                                                 ids2[col_leader]), "grid_create_rccl")
+        else:
+            import torch
+            groups = {ROW: pg["row"], COL: pg["col"]}
+            row_ranks = [self.myrow + j * nprow for j in range(npcol)]
+            col_ranks = [i + self.mycol * nprow for i in range(nprow)]
+
+            def _ar(user, group, buf, count):
+                try:
+                    t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(count,)))
+                    dist.all_reduce(t, group=groups[group])
+                    return 0
+                except Exception as e:  # pragma: no cover
+                    print("allreduce callback failed:", e, flush=True)
+                    return 1
+
+            def _bc(user, group, buf, count, root):
+                try:
+                    t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(count,)))
+                    src = (row_ranks if group == ROW else col_ranks)[root]
+                    dist.broadcast(t, src=src, group=groups[group])
+                    return 0
+                except Exception as e:  # pragma: no cover
+                    print("bcast callback failed:", e, flush=True)
+                    return 1
+
+            self._cb = (AR_FN(_ar), BC_FN(_bc))          # keep the thunks alive
+            check(lib.chase_hip_grid_create_host(C.byref(h), ctx.h, nprow, npcol, rank, self._cb[0], self._cb[1], None),
+                  "grid_create_host")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.chase_hip_grid_destroy(self.h)
+            self.h = None
+
+
+def make_process_groups(nprow, npcol):
+    """Row / column torch.distributed groups; every rank must create all of them in the same order."""
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    myrow, mycol = coords_of(rank, nprow)
+    out = {"world": dist.group.WORLD}
+    for i in range(nprow):
+        g = dist.new_group([i + j * nprow for j in range(npcol)])
+        if i == myrow:
+            out["row"] = g
+    for j in range(npcol):
+        g = dist.new_group([i + j * nprow for i in range(nprow)])
+        if j == mycol:
+            out["col"] = g
+    return out
+
+
+class DistSolver:
+    """pChaseHip<T> behind the C ABI (collective: every rank of the grid constructs it and calls the same methods)."""
+
+    def __init__(self, ctx, grid, dH_loc, N, nev, nex, cplx, mb=0, nb=0, ldh=None):
+        self.ctx, self.grid, self.N, self.nev, self.nex, self.cplx = ctx, grid, N, nev, nex, bool(cplx)
+        self.ritzv = np.zeros(nev + nex)
+        h = c_void_p()
+        ptr = dH_loc.ptr if isinstance(dH_loc, DeviceArray) else dH_loc
+        ldh = ldh or (dH_loc.ld if isinstance(dH_loc, DeviceArray) else None)
+        check(lib.chase_hip_psolver_create(C.byref(h), ctx.h, grid.h, int(cplx), N, nev, nex, mb, nb, ptr, ldh,
+                                           self.ritzv.ctypes.data), "psolver_create")
+        self.h = h
+        m, n = c_size_t(), c_size_t()
+        check(lib.chase_hip_psolver_local_shape(h, C.byref(m), C.byref(n)), "local_shape")
+        self.m_loc, self.n_loc = m.value, n.value
+        self.dt = np.complex128 if cplx else np.float64
+
+    def close(self):
+        if self.h:
+            lib.chase_hip_solver_destroy(self.h)
+            self.h = None
+
+    def set(self, **kw):
+        for k, v in kw.items():
+            if k == "pipeline":
+                check(lib.chase_hip_psolver_set_pipeline(self.h, int(v)), "set_pipeline")
+            else:
+                check(lib.chase_hip_solver_set(self.h, k.encode(), float(v)), f"solver_set({k})")
+
+    def get(self, key):
+        v = c_double()
+        check(lib.chase_hip_solver_get(self.h, key.encode(), C.byref(v)), f"solver_get({key})")
+        return v.value
+
+    def solve(self, trace=False):
+        check(lib.chase_hip_solver_solve(self.h, int(trace)), "solver_solve")
+        s = Stats()
+        check(lib.chase_hip_solver_stats(self.h, C.byref(s)), "solver_stats")
+        return s.as_dict()
+
+    def resid(self):
+        p = lib.chase_hip_solver_resid(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.nev + self.nex,)).copy()
+
+    def trace(self):
+        return lib.chase_hip_solver_trace(self.h).decode().splitlines()
+
+    def local_V(self):
+        out = np.empty((self.m_loc, self.nev + self.nex), dtype=self.dt, order="F")
+        check(lib.chase_hip_psolver_download_v(self.h, out.ctypes.data, self.m_loc), "download_v")
+        return out
+
+    def upload_local_V(self, V):
+        V = np.asfortranarray(V, dtype=self.dt)
+        check(lib.chase_hip_psolver_upload_v(self.h, V.ctypes.data, V.shape[0]), "upload_v")
+
+    # ChaseBase virtuals (collective)
+    def Start(self): check(lib.chase_hip_op_start(self.h), "Start")
+    def End(self): check(lib.chase_hip_op_end(self.h), "End")
+    def initVecs(self, random): check(lib.chase_hip_op_initvecs(self.h, int(random)), "initVecs")
+    def Shift(self, c, isunshift=False): check(lib.chase_hip_op_shift(self.h, float(c), int(isunshift)), "Shift")
+
+    def HEMM(self, block, alpha, beta, offset_left, offset_right=0):
+        check(lib.chase_hip_op_hemm(self.h, block, _z2(alpha), _z2(beta), offset_left, offset_right), "HEMM")
+
+    def QR(self, fixednev, cond): check(lib.chase_hip_op_qr(self.h, fixednev, float(cond)), "QR")
+    def RR(self, block, offset): check(lib.chase_hip_op_rr(self.h, self.ritzv.ctypes.data + 8 * offset, block), "RR")
+
+    def Resd(self, offset):
+        out = np.zeros(self.nev + self.nex - offset)
+        check(lib.chase_hip_op_resd(self.h, self.ritzv.ctypes.data + 8 * offset, out.ctypes.data, offset), "Resd")
+        return out
+
+    def Swap(self, i, j): check(lib.chase_hip_op_swap(self.h, i, j), "Swap")
+    def Lock(self, n): check(lib.chase_hip_op_lock(self.h, n), "Lock")
+
+    def Lanczos(self, M, numvec):
+        ub = c_double()
+        theta, tau, ritzV = np.zeros(M * numvec), np.zeros(M * numvec), np.zeros(M * M)
+        check(lib.chase_hip_op_lanczos(self.h, M, numvec, C.byref(ub), theta.ctypes.data, tau.ctypes.data,
+                                       ritzV.ctypes.data), "Lanczos")
+        return ub.value, theta, tau, ritzV.reshape(M, M, order="F")
+
+
+def local_block_of(H, rl, cl, myrow, mycol):
+    """Extract this rank's block of a full host matrix (tests)."""
+    return np.asfortranarray(H[np.ix_(rl.globals_of(myrow), cl.globals_of(mycol))])
+
+
+def gen_clement_local(ctx, N, cplx, rl, cl, myrow, mycol, scale=1.0, perturb=0.0, seed=42):
+    """This rank's shard of the Clement-type test matrix, generated in HBM."""
+    m, n = rl.count(myrow), cl.count(mycol)
+    dH = ctx.empty((m, n), np.complex128 if cplx else np.float64)
+    check(lib.chase_hip_gen_clement(ctx.h, int(cplx), dH.ptr, m, m, n, N, rl.nb, rl.p, myrow, 0, cl.nb, cl.p, mycol, 0,
+                                    float(scale), float(perturb), seed), "gen_clement")
+    return dH

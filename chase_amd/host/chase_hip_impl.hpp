@@ -35,8 +35,21 @@ struct HipStatusError : std::runtime_error {
 };
 inline void hip_ok(int rc, const char* where) { if (rc < 0) throw HipStatusError(rc, where); }
 
+// what the C entry points and the bench need beyond the ChaseBase surface, common to both Impls
+struct HipImplExtras {
+    virtual ~HipImplExtras() = default;
+    virtual std::size_t locked() const = 0;
+    virtual int last_qr_variant() const = 0;     // 0 = Householder, 1/2/3 = CholQR1 / CholQR2 / shifted CholQR2
+    virtual double filter_ms() const = 0;        // HIP-event time between FilterPhaseStart/End, accumulated
+    virtual std::size_t hemm_calls() const = 0;
+    virtual void set_device_rng(bool) = 0;
+    virtual void reset_counters() = 0;
+    virtual void* device_V1() = 0;               // current (local) vector block, pending swaps applied
+    virtual std::size_t local_rows() const = 0;
+};
+
 template <class T, class BaseT = ChaseBase<T>, class ConfigT = ChaseConfig<T>>
-class ChaseHip : public BaseT {
+class ChaseHip : public BaseT, public HipImplExtras {
 public:
     using R = Base<T>;
     static constexpr int CP = is_cplx<T>::value ? 1 : 0;
@@ -86,11 +99,12 @@ public:
     }
     void set_early_locked_residuals(std::vector<R> r) override { early_ = std::move(r); }
     const std::vector<R>& early_locked_residuals() const { return early_; }
-    std::size_t locked() const { return locked_; }
-    T* device_V1() { flush_swaps(); return dV1_; }
+    std::size_t locked() const override { return locked_; }
+    void* device_V1() override { flush_swaps(); return dV1_; }
+    std::size_t local_rows() const override { return N_; }
     T* device_V2() { return dV2_; }
     T* device_H() { return dH_; }
-    double filter_ms() const { return filter_ms_; }
+    double filter_ms() const override { return filter_ms_; }
 
     // randomized Hermiticity check: ||H v - H^H v|| small  (reference: cpu::checkSymmetryEasy, symOrHerm.hpp)
     bool checkSymmetryEasy() override
@@ -171,9 +185,9 @@ public:
     }
     // true: initVecs(random) draws N(0,1) on the device like ChASEGPU; false (default): mt19937(1337) on the host,
     // bitwise the start vectors of ChASECPU (used by the parity tests)
-    void set_device_rng(bool f) { device_rng_ = f; }
-    void reset_counters() { filter_ms_ = 0; hemm_calls_ = 0; }
-    std::size_t hemm_calls() const { return hemm_calls_; }
+    void set_device_rng(bool f) override { device_rng_ = f; }
+    void reset_counters() override { filter_ms_ = 0; hemm_calls_ = 0; }
+    std::size_t hemm_calls() const override { return hemm_calls_; }
 
     void Shift(T c, bool = false) override
     {
@@ -215,7 +229,7 @@ public:
         }
         hip_ok(chase_hip_lacpy(ctx_, CP, (int)N_, (int)locked_, dV2_, (long)N_, dV1_, (long)N_), "lacpy");
     }
-    int last_qr_variant() const { return last_qr_variant_; }   // 0 = Householder, 1/2/3 = CholQR1/2/shifted
+    int last_qr_variant() const override { return last_qr_variant_; }
 
     // ---- Rayleigh-Ritz (cpu/rayleighRitz.hpp:61-112 + chase_cpu.hpp:778-798) -----------------------------------------
     void RR(R* ritzv, std::size_t block) override

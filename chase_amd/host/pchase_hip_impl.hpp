@@ -1,0 +1,610 @@
+// pchase_hip_impl.hpp — pChaseHip<T, BaseT>: multi-GPU implementation of the ChaseBase<T> operator surface on a 2D
+// process grid, one process per MI355X, collectives over RCCL/xGMI.
+//
+// Semantics follow the reference's distributed Impls virtual by virtual
+//   Impl/pchase_cpu/pchase_cpu.hpp:92-1129 (pChASECPU)  and  Impl/pchase_gpu/pchase_gpu.hpp:119-1804 (pChASEGPU<NCCL>)
+// and their kernels
+//   HEMM           linalg/internal/mpi/hemm.hpp:46-230        (column-type <-> row-type, beta on grid row/col 0, all-reduce)
+//   CholQR         linalg/internal/mpi/cholqr.hpp:51-397      (Gram all-reduce over the column communicator)
+//   Rayleigh-Ritz  linalg/internal/mpi/rayleighRitz.hpp:103-186
+//   residuals      linalg/internal/mpi/residuals.hpp:61-107
+//   Lanczos        linalg/internal/mpi/lanczos.hpp:153-370
+//   redistribution linalg/distMatrix/distMultiVector.hpp:2444-2720 (one packed broadcast per source rank here,
+//                  instead of one per contiguous run: 2 instead of 1024 for block-cyclic nb = 64 at N = 65536)
+// Data distribution: H block-cyclic (mb x nb; a block layout is mb = block length) over nprow x npcol;
+// "column-type" multivectors V1/V2 are split like H's rows over the grid rows and replicated over grid columns,
+// "row-type" W1/W2 are split like H's columns over the grid columns and replicated over grid rows.
+//
+// MI355X-first differences from the reference (results equal up to rounding):
+//   * the filter HEMM is panel-pipelined: the all-reduce of column panel p runs on the communication stream while the
+//     MFMA GEMM of panel p+1 runs on the compute stream, and the next filter step's GEMM on panel p waits only for
+//     panel p's all-reduce (the reference left this as commented-out code, linalg/internal/nccl/hemm.hpp:97-288);
+//   * host control flow (potrf info, Ritz values, residuals) is made identical on all ranks by tiny agreement
+//     collectives instead of relying on bitwise-identical replicas;
+//   * Swap() is deferred into one column permutation, Lanczos scalars stay on the device.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <stdexcept>
+#include <vector>
+#include "../../include/chase_hip.h"
+#include "../../include/chase_hip_grid.h"
+#include "chase_hip_impl.hpp"
+#include "interface.hpp"
+
+namespace chase_amd {
+
+template <class T, class BaseT = ChaseBase<T>, class ConfigT = ChaseConfig<T>>
+class pChaseHip : public BaseT, public HipImplExtras {
+public:
+    using R = Base<T>;
+    static constexpr int CP = is_cplx<T>::value ? 1 : 0;
+    static constexpr int E = CP ? 2 : 1;
+    static constexpr std::size_t PANEL = 256;        // fixed column grid of the pipelined HEMM
+
+    struct Dim {                                      // 1D block-cyclic distribution of N indices over p ranks
+        long N = 0, nb = 1; int p = 1, q = 0; long nloc = 0;
+        int owner(long g) const { return chase_hip_owner(g, nb, p); }
+        long local(long g) const { return chase_hip_local_index(g, nb, p); }
+        long global(long l, int iq) const { return chase_hip_global_index(l, nb, iq, p); }
+        long count(int iq) const { return chase_hip_numroc(N, nb, iq, p); }
+    };
+
+    // H_loc: DEVICE pointer to this rank's m_loc x n_loc block (ldh >= m_loc).  mb = nb = 0 selects the block layout.
+    pChaseHip(chase_hip_ctx* ctx, chase_hip_grid* grid, std::size_t N, std::size_t nev, std::size_t nex, std::size_t mb,
+              std::size_t nb, T* H_loc, std::size_t ldh, R* ritzv)
+        : ctx_(ctx), grid_(grid), N_(N), nev_(nev), nex_(nex), nevex_(nev + nex), dH_(H_loc), ldh_(ldh), ritzv_(ritzv),
+          config_(N, nev, nex), resid_(nev + nex, 0), perm_(nev + nex)
+    {
+        if (!ctx || !grid || !H_loc || !ritzv) throw std::invalid_argument("pChaseHip: null argument");
+        if (N == 0 || nevex_ == 0 || nevex_ > N) throw std::invalid_argument("pChaseHip: need 0 < nev+nex <= N");
+        hip_ok(chase_hip_grid_info(grid, &nprow_, &npcol_, &myrow_, &mycol_), "grid_info");
+        Rr_.N = Cc_.N = (long)N;
+        Rr_.p = nprow_; Rr_.q = myrow_; Cc_.p = npcol_; Cc_.q = mycol_;
+        Rr_.nb = mb ? (long)mb : chase_hip_block_len((long)N, nprow_);
+        Cc_.nb = nb ? (long)nb : chase_hip_block_len((long)N, npcol_);
+        Rr_.nloc = Rr_.count(myrow_);
+        Cc_.nloc = Cc_.count(mycol_);
+        m_ = (std::size_t)Rr_.nloc; n_ = (std::size_t)Cc_.nloc;
+        if (ldh < m_) throw std::invalid_argument("pChaseHip: ldh smaller than the local row count");
+        if (m_ == 0 || n_ == 0) throw std::invalid_argument("pChaseHip: empty local block (grid too large for N)");
+        for (std::size_t i = 0; i < nevex_; ++i) perm_[i] = (int)i;
+        alloc((void**)&dV1_, m_ * nevex_ * sizeof(T));
+        alloc((void**)&dV2_, m_ * nevex_ * sizeof(T));
+        alloc((void**)&dVt_, m_ * nevex_ * sizeof(T));
+        alloc((void**)&dW1_, n_ * nevex_ * sizeof(T));
+        alloc((void**)&dW2_, n_ * nevex_ * sizeof(T));
+        alloc((void**)&dA_, nevex_ * nevex_ * sizeof(T));
+        pack_elems_ = nevex_ * nevex_ + 64 * nevex_ + 64;          // packed Gram triangle / agreement scratch
+        alloc((void**)&dPack_, pack_elems_ * sizeof(T));
+        // staging must hold the largest block of ANY rank (rank 0 of a dimension owns the most rows)
+        alloc((void**)&dStage_, (std::size_t)std::max(Rr_.count(0), Cc_.count(0)) * nevex_ * sizeof(T));
+        build_diag_lists();
+        build_redistribution();
+    }
+    ~pChaseHip() override { for (void* p : owned_) chase_hip_free(ctx_, p); }
+
+    // ---- getters -----------------------------------------------------------------------------------------------------
+    std::size_t GetN() const override { return N_; }
+    std::size_t GetNev() override { return nev_; }
+    std::size_t GetNex() override { return nex_; }
+    std::size_t GetLanczosIter() override { return lanczosIter_; }
+    std::size_t GetNumLanczos() override { return numLanczos_; }
+    std::size_t GetRitzvBlockSize() const override { return nevex_; }
+    R* GetRitzv() override { return ritzv_; }
+    R* GetResid() override { return resid_.data(); }
+    ConfigT& GetConfig() override { return config_; }
+    int get_nprocs() override { return nprow_ * npcol_; }
+    int get_rank() override { return myrow_ + mycol_ * nprow_; }
+    bool isSym() override { return true; }
+    bool isPseudoHerm() override { return false; }
+    bool checkPseudoHermicityEasy() override { return false; }
+    bool checkSymmetryEasy() override { return true; }   // TODO(next): distributed randomized check
+    void symOrHermMatrix(char) override { throw std::logic_error("pChaseHip: symOrHermMatrix not available on shards"); }
+    void Sort(R*, R*, R*) override {}
+    void ApplyKconjugate(std::size_t) override {}
+    void HEMM_H2(std::size_t, T, T, T, std::size_t, std::size_t = 0) override
+    {
+        throw std::logic_error("pChaseHip: HEMM_H2 belongs to the pseudo-Hermitian Impl");
+    }
+    void set_early_locked_residuals(std::vector<R> r) override { early_ = std::move(r); }
+
+    // HipImplExtras
+    std::size_t locked() const override { return locked_; }
+    int last_qr_variant() const override { return last_qr_variant_; }
+    double filter_ms() const override { return filter_ms_; }
+    std::size_t hemm_calls() const override { return hemm_calls_; }
+    void set_device_rng(bool f) override { device_rng_ = f; }
+    void reset_counters() override { filter_ms_ = 0; hemm_calls_ = 0; }
+    void* device_V1() override { flush_swaps(); sync_comm(); return dV1_; }
+    std::size_t local_rows() const override { return m_; }
+    std::size_t local_cols_h() const { return n_; }
+    void set_pipeline(bool f) { pipeline_ = f; }
+
+    // ---- life cycle ----------------------------------------------------------------------------------------------------
+    void Start() override { locked_ = 0; }
+
+    // pchase_cpu.hpp:272-311: every grid row seeds mt19937(1337 + coords[0]) and fills its block in memory order
+    void initVecs(bool random) override
+    {
+        if (random) {
+            if (device_rng_) {
+                hip_ok(chase_hip_fill_normal_bc(ctx_, CP, (int)m_, (int)nevex_, dV1_, (long)m_, (long)N_, (int)Rr_.nb,
+                                                nprow_, myrow_, 1337ull), "fill_normal_bc");
+            } else {
+                std::vector<T> h(m_ * nevex_);
+                std::mt19937 gen(1337.0 + myrow_);
+                std::normal_distribution<> d;
+                for (auto& x : h) x = rnd(d, gen);
+                hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)m_, (int)nevex_, h.data(), (long)m_, dV1_, (long)m_), "upload V");
+            }
+        }
+        hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)nevex_, dV1_, (long)m_, dV2_, (long)m_), "lacpy");
+        reset_perm();
+        next_bAc_ = true;
+    }
+    // caller-provided start vectors (approximate-solution mode): local m_loc x nevex block, host memory
+    void upload_local_V(const T* host, std::size_t ldv)
+    {
+        hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)m_, (int)nevex_, host, (long)ldv, dV1_, (long)m_), "upload V");
+    }
+    void download_local_V(T* host, std::size_t ldv)
+    {
+        flush_swaps(); sync_comm();
+        hip_ok(chase_hip_download_matrix(ctx_, CP, (int)m_, (int)nevex_, dV1_, (long)m_, host, (long)ldv), "download V");
+    }
+    void End() override { flush_swaps(); sync_comm(); hip_ok(chase_hip_ctx_sync(ctx_), "sync"); }
+
+    // ---- filter --------------------------------------------------------------------------------------------------------
+    void FilterPhaseStart() override
+    {
+        flush_swaps();
+        chase_hip_ctx_set_phase(ctx_, 1);
+        hip_ok(chase_hip_timer_start(ctx_), "timer");
+    }
+    void FilterPhaseEnd() override
+    {
+        sync_comm();
+        float ms = 0;
+        hip_ok(chase_hip_timer_stop(ctx_, &ms), "timer");
+        chase_hip_ctx_set_phase(ctx_, 0);
+        filter_ms_ += ms;
+    }
+
+    // mpi/shiftDiagonal.hpp:21-78 / cuda/shiftDiagonal.cu:100-149: shift the locally owned diagonal entries
+    void Shift(T c, bool isunshift = false) override
+    {
+        if (isunshift) next_bAc_ = true;
+        hip_ok(chase_hip_shift_list(ctx_, CP, dH_, (long)ldh_, d_diag_rows_, d_diag_cols_, (int)diag_cnt_, std::real(c)),
+               "shift_list");
+    }
+
+    void HEMM(std::size_t block, T alpha, T beta, std::size_t offset_left, std::size_t offset_right = 0) override
+    {
+        flush_swaps();
+        const std::size_t ncols = (offset_right < block) ? block - offset_right : 0;
+        if (ncols != 0) {
+            hemm_dir(next_bAc_, locked_ + offset_left, ncols, alpha, beta, true);
+            ++hemm_calls_;
+        }
+        next_bAc_ = !next_bAc_;
+    }
+
+    // ---- QR (pchase_cpu.hpp:572-867) -------------------------------------------------------------------------------------
+    void QR(std::size_t, R cond) override
+    {
+        flush_swaps(); sync_comm();
+        hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)locked_, dV1_, (long)m_, dV2_, (long)m_), "lacpy");
+        int disable = config_.DoCholQR() ? 0 : 1;
+        if (const char* s = std::getenv("CHASE_DISABLE_CHOLQR")) disable = std::atoi(s);
+        R thld_hi = 1e8, thld_lo = 2e1;
+        if (const char* s = std::getenv("CHASE_CHOLQR1_THLD")) thld_lo = std::atof(s);
+        last_qr_variant_ = 0;
+        if (disable == 1 && cond != (R)1.0) {
+            householder();
+        } else {
+            const int variant = (cond > thld_hi) ? 3 : (cond < thld_lo ? 1 : 2);
+            last_qr_variant_ = variant;
+            if (cholqr_dist(variant) != 0) householder();
+        }
+        hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)locked_, dV2_, (long)m_, dV1_, (long)m_), "lacpy");
+        const std::size_t un = nevex_ - locked_;
+        hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)un, dV1_ + locked_ * m_, (long)m_, dV2_ + locked_ * m_, (long)m_), "lacpy");
+    }
+
+    // ---- Rayleigh-Ritz (mpi/rayleighRitz.hpp:103-186 + pchase_cpu.hpp:869-896) ------------------------------------------
+    void RR(R* ritzv, std::size_t block) override
+    {
+        flush_swaps(); sync_comm();
+        const std::size_t c0 = locked_;
+        // replicas of V over the grid columns are re-synchronised like the reference does (pchase_gpu.hpp:1631-1633)
+        coll(chase_hip_grid_bcast(grid_, CHASE_HIP_ROW, dV1_ + c0 * m_, m_ * block * E, 0, 0));
+        hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)block, dV1_ + c0 * m_, (long)m_, dV2_ + c0 * m_, (long)m_), "lacpy");
+        hemm_dir(true, c0, block, T(1), T(0), false);                        // W1 = H^H V1 (row-type), all-reduced
+        redistribute_c2r(dV2_ + c0 * m_, dW2_ + c0 * n_, block);             // W2 = V2 in the row-type layout
+        gemm('C', block, block, n_, T(1), dW2_ + c0 * n_, n_, dW1_ + c0 * n_, n_, T(0), dA_, block);
+        allreduce_packed_upper(dA_, block, CHASE_HIP_ROW);
+        hip_ok(chase_hip_heevd(ctx_, CP, (int)block, dA_, (long)block, ritzv), "heevd");
+        agree_vector(ritzv, block, dA_, block * block);                      // identical Ritz pairs on every rank
+        gemm('N', m_, block, block, T(1), dV2_ + c0 * m_, m_, dA_, block, T(0), dV1_ + c0 * m_, m_);
+        hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)block, dV1_ + c0 * m_, (long)m_, dV2_ + c0 * m_, (long)m_), "lacpy");
+    }
+
+    // ---- residuals (mpi/residuals.hpp:61-107) ----------------------------------------------------------------------------
+    void Resd(R* ritzv, R* resd, std::size_t) override
+    {
+        flush_swaps(); sync_comm();
+        const std::size_t c0 = locked_, sub = nevex_ - locked_;
+        hemm_dir(true, c0, sub, T(1), T(0), false);                          // W1 = H^H V1
+        redistribute_c2r(dV2_ + c0 * m_, dW2_ + c0 * n_, sub);               // W2 = V2 (== V1) row-type
+        hip_ok(chase_hip_resid_norms(ctx_, CP, (int)n_, (int)sub, dW1_ + c0 * n_, (long)n_, dW2_ + c0 * n_, (long)n_,
+                                     ritzv, resd, 1), "resid_norms");      // local sums of squares
+        // all-reduce over the row communicator, then sqrt (mpi/residuals.hpp:99-105)
+        double* d = (double*)dPack_;
+        hip_ok(chase_hip_memcpy_h2d(ctx_, d, resd, sub * sizeof(double)), "h2d");
+        coll(chase_hip_grid_allreduce(grid_, CHASE_HIP_ROW, d, sub, 0));
+        hip_ok(chase_hip_memcpy_d2h(ctx_, resd, d, sub * sizeof(double)), "d2h");
+        for (std::size_t i = 0; i < sub; ++i) resd[i] = std::sqrt(resd[i]);
+        agree_vector(resd, sub, nullptr, 0);
+        if (resd != resid_.data() + locked_) std::memcpy(resid_.data() + locked_, resd, sub * sizeof(R));
+    }
+
+    void Swap(std::size_t i, std::size_t j) override
+    {
+        if (i == j) return;
+        std::swap(perm_[i], perm_[j]);
+        perm_dirty_ = true;
+    }
+    void Lock(std::size_t k) override { locked_ += k; }
+
+    // ---- Lanczos (mpi/lanczos.hpp:153-370) ---------------------------------------------------------------------------------
+    void Lanczos(std::size_t m, R* upperb) override
+    {
+        lanczosIter_ = m; numLanczos_ = 1;
+        std::vector<R> theta(m);
+        lanczos_core(m, 1, false, upperb, theta.data(), nullptr, nullptr);
+    }
+    void Lanczos(std::size_t M, std::size_t numvec, R* upperb, R* ritzv, R* Tau, R* ritzV) override
+    {
+        lanczosIter_ = M; numLanczos_ = numvec;
+        lanczos_core(M, numvec, true, upperb, ritzv, Tau, ritzV);
+    }
+    void LanczosDos(std::size_t idx, std::size_t m, T* ritzVc) override
+    {
+        flush_swaps(); sync_comm();
+        hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)m, (int)idx, ritzVc, (long)m, dA_, (long)m), "upload ritzV");
+        gemm('N', m_, idx, m, T(1), dV1_, m_, dA_, m, T(0), dV2_, m_);
+        hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)m, dV2_, (long)m_, dV1_, (long)m_), "lacpy");
+    }
+
+private:
+    static T rnd(std::normal_distribution<>& d, std::mt19937& g)
+    {
+        if constexpr (is_cplx<T>::value) { const double re = d(g); const double im = d(g); return T(re, im); }
+        else return T(d(g));
+    }
+    void alloc(void** p, std::size_t bytes)
+    {
+        int rc = chase_hip_malloc(ctx_, p, bytes);
+        if (rc) throw HipStatusError(rc, "chase_hip_malloc");
+        owned_.push_back(*p);
+    }
+    int* upload_ints(const std::vector<int>& v)
+    {
+        int* d = nullptr;
+        alloc((void**)&d, std::max<std::size_t>(v.size(), 1) * sizeof(int));
+        if (!v.empty()) hip_ok(chase_hip_memcpy_h2d(ctx_, d, v.data(), v.size() * sizeof(int)), "h2d");
+        return d;
+    }
+    static void coll(int rc) { if (rc) throw HipStatusError(rc, "collective"); }
+    void sync_comm() { coll(chase_hip_grid_wait(grid_)); }
+    void gemm(char op, std::size_t m, std::size_t n, std::size_t k, T alpha, const T* A, std::size_t lda, const T* B,
+              std::size_t ldb, T beta, T* C, std::size_t ldc)
+    {
+        int rc;
+        if constexpr (is_cplx<T>::value) {
+            const double a[2] = {alpha.real(), alpha.imag()}, b[2] = {beta.real(), beta.imag()};
+            rc = chase_hip_gemm_z(ctx_, op, (int)m, (int)n, (int)k, a, A, (long)lda, B, (long)ldb, b, C, (long)ldc);
+        } else {
+            rc = chase_hip_gemm_d(ctx_, op, (int)m, (int)n, (int)k, alpha, A, (long)lda, B, (long)ldb, beta, C, (long)ldc);
+        }
+        hip_ok(rc, "gemm");
+    }
+
+    // local (row, col) positions of the global diagonal inside this rank's block (pchase_gpu.hpp:340-409)
+    void build_diag_lists()
+    {
+        std::vector<int> rows, cols;
+        for (long l = 0; l < Rr_.nloc; ++l) {
+            const long g = Rr_.global(l, myrow_);
+            if (g < (long)N_ && Cc_.owner(g) == mycol_) { rows.push_back((int)l); cols.push_back((int)Cc_.local(g)); }
+        }
+        diag_cnt_ = rows.size();
+        d_diag_rows_ = upload_ints(rows);
+        d_diag_cols_ = upload_ints(cols);
+    }
+
+    struct Xfer { int root = 0; int cnt = 0; int* d_src = nullptr; int* d_dst = nullptr; };
+    // One packed broadcast per source rank.  c2r (column-type -> row-type) runs inside my column group: every member
+    // needs the same row-type block (global rows owned by grid column mycol), gathered from the members' column-type rows.
+    void build_redistribution()
+    {
+        for (int ip = 0; ip < nprow_; ++ip) {
+            std::vector<int> src, dst;
+            for (long g = 0; g < (long)N_; ++g)
+                if (Rr_.owner(g) == ip && Cc_.owner(g) == mycol_) { src.push_back((int)Rr_.local(g)); dst.push_back((int)Cc_.local(g)); }
+            Xfer x; x.root = ip; x.cnt = (int)src.size();
+            if (x.cnt) { x.d_src = upload_ints(src); x.d_dst = upload_ints(dst); c2r_.push_back(x); }
+        }
+        for (int jp = 0; jp < npcol_; ++jp) {
+            std::vector<int> src, dst;
+            for (long g = 0; g < (long)N_; ++g)
+                if (Cc_.owner(g) == jp && Rr_.owner(g) == myrow_) { src.push_back((int)Cc_.local(g)); dst.push_back((int)Rr_.local(g)); }
+            Xfer x; x.root = jp; x.cnt = (int)src.size();
+            if (x.cnt) { x.d_src = upload_ints(src); x.d_dst = upload_ints(dst); r2c_.push_back(x); }
+        }
+        // global row of every local column-type row, per grid row (Householder fallback gathers the full vectors)
+        for (int ip = 0; ip < nprow_; ++ip) {
+            std::vector<int> gl((std::size_t)Rr_.count(ip));
+            for (std::size_t l = 0; l < gl.size(); ++l) gl[l] = (int)Rr_.global((long)l, ip);
+            d_rowmap_.push_back(upload_ints(gl));
+            rowmap_cnt_.push_back((int)gl.size());
+        }
+    }
+    // dst (row-type, ld n_) <- src (column-type, ld m_), ncols columns
+    void redistribute_c2r(const T* src, T* dst, std::size_t ncols)
+    {
+        for (const Xfer& x : c2r_) {
+            if (myrow_ == x.root)
+                hip_ok(chase_hip_rows_indexed(ctx_, CP, src, (long)m_, dStage_, x.cnt, x.d_src, x.cnt, (int)ncols, 0), "pack");
+            coll(chase_hip_grid_bcast(grid_, CHASE_HIP_COL, dStage_, (std::size_t)x.cnt * ncols * E, x.root, 0));
+            hip_ok(chase_hip_rows_indexed(ctx_, CP, dStage_, x.cnt, dst, (long)n_, x.d_dst, x.cnt, (int)ncols, 1), "unpack");
+        }
+    }
+    // dst (column-type, ld m_) <- src (row-type, ld n_)
+    void redistribute_r2c(const T* src, T* dst, std::size_t ncols)
+    {
+        for (const Xfer& x : r2c_) {
+            if (mycol_ == x.root)
+                hip_ok(chase_hip_rows_indexed(ctx_, CP, src, (long)n_, dStage_, x.cnt, x.d_src, x.cnt, (int)ncols, 0), "pack");
+            coll(chase_hip_grid_bcast(grid_, CHASE_HIP_ROW, dStage_, (std::size_t)x.cnt * ncols * E, x.root, 0));
+            hip_ok(chase_hip_rows_indexed(ctx_, CP, dStage_, x.cnt, dst, (long)m_, x.d_dst, x.cnt, (int)ncols, 1), "unpack");
+        }
+    }
+
+    // one direction of the distributed HEMM on columns [c0, c0 + nc)  (mpi/hemm.hpp:114-229)
+    //   bAc:  W1 = alpha * H_loc^H * V1 + beta' * W1,  beta' = beta on grid row 0 only,  all-reduce over the column group
+    //   cAb:  V1 = alpha * H_loc   * W1 + beta' * V1,  beta' = beta on grid col 0 only,  all-reduce over the row group
+    void hemm_dir(bool bAc, std::size_t c0, std::size_t nc, T alpha, T beta, bool pipelined)
+    {
+        const int group = bAc ? CHASE_HIP_COL : CHASE_HIP_ROW;
+        const bool root = bAc ? (myrow_ == 0) : (mycol_ == 0);
+        const T b = root ? beta : T(0);
+        const std::size_t out_ld = bAc ? n_ : m_;
+        T* out = bAc ? dW1_ : dV1_;
+        const T* in = bAc ? dV1_ : dW1_;
+        const std::size_t in_ld = bAc ? m_ : n_;
+        const bool pipe = pipelined && pipeline_ && (bAc ? nprow_ : npcol_) > 1;
+        std::size_t c = c0;
+        while (c < c0 + nc) {
+            const std::size_t fp = c / PANEL;                                  // fixed panel index
+            const std::size_t cend = pipe ? std::min(c0 + nc, (fp + 1) * PANEL) : c0 + nc;
+            const std::size_t w = cend - c;
+            if (pipe) coll(chase_hip_grid_event_wait(grid_, (int)fp));         // previous step's all-reduce of my input
+            if (bAc) gemm('C', n_, w, m_, alpha, dH_, ldh_, in + c * in_ld, in_ld, b, out + c * out_ld, out_ld);
+            else     gemm('N', m_, w, n_, alpha, dH_, ldh_, in + c * in_ld, in_ld, b, out + c * out_ld, out_ld);
+            coll(chase_hip_grid_allreduce(grid_, group, out + c * out_ld, out_ld * w * E, pipe ? 1 : 0));
+            if (pipe) coll(chase_hip_grid_event_record(grid_, (int)fp));
+            c = cend;
+        }
+    }
+
+    // A (n x n, Hermitian, device) <- sum over `group` of A, moving only the packed upper triangle
+    void allreduce_packed_upper(T* A, std::size_t n, int group)
+    {
+        hip_ok(chase_hip_pack_upper(ctx_, CP, (int)n, A, (long)n, dPack_), "pack_upper");
+        coll(chase_hip_grid_allreduce(grid_, group, dPack_, n * (n + 1) / 2 * E, 0));
+        hip_ok(chase_hip_unpack_upper(ctx_, CP, (int)n, dPack_, A, (long)n, 1), "unpack_upper");
+    }
+
+    // make a small host vector (and optionally a device matrix) identical on all ranks: broadcast from grid (0, 0)
+    void agree_vector(R* host, std::size_t n, T* dev, std::size_t dev_elems)
+    {
+        if (nprow_ * npcol_ == 1) return;
+        if (n > pack_elems_ * E) throw std::length_error("pChaseHip: agreement scratch too small");
+        double* d = (double*)dPack_;
+        hip_ok(chase_hip_memcpy_h2d(ctx_, d, host, n * sizeof(double)), "h2d");
+        coll(chase_hip_grid_bcast(grid_, CHASE_HIP_COL, d, n, 0, 0));
+        coll(chase_hip_grid_bcast(grid_, CHASE_HIP_ROW, d, n, 0, 0));
+        hip_ok(chase_hip_memcpy_d2h(ctx_, host, d, n * sizeof(double)), "d2h");
+        if (dev && dev_elems) {
+            coll(chase_hip_grid_bcast(grid_, CHASE_HIP_COL, dev, dev_elems * E, 0, 0));
+            coll(chase_hip_grid_bcast(grid_, CHASE_HIP_ROW, dev, dev_elems * E, 0, 0));
+        }
+    }
+
+    // mpi/cholqr.hpp:51-397 on the column-type V1 (all nevex columns); returns the agreed potrf info
+    int cholqr_dist(int variant)
+    {
+        const int n = (int)nevex_;
+        const int passes = variant == 1 ? 1 : (variant == 2 ? 2 : 3);
+        int info = 0;
+        for (int ps = 0; ps < passes; ++ps) {
+            hip_ok(chase_hip_herk(ctx_, CP, n, (int)m_, dV1_, (long)m_, dA_, (long)n), "herk");
+            allreduce_packed_upper(dA_, nevex_, CHASE_HIP_COL);
+            if (variant == 3 && ps == 0) {
+                double nrmf = 0;
+                hip_ok(chase_hip_abs_trace(ctx_, CP, n, dA_, (long)n, &nrmf), "abs_trace");
+                const double shift = std::sqrt((double)N_) * nrmf * std::numeric_limits<double>::epsilon();
+                hip_ok(chase_hip_shift_diag(ctx_, CP, n, dA_, (long)n, shift), "shift");
+            }
+            info = chase_hip_potrf_upper(ctx_, CP, n, dA_, (long)n);
+            hip_ok(info, "potrf");
+            coll(chase_hip_grid_agree_max(grid_, &info));
+            if (ps == 0 && info != 0) return info;
+            hip_ok(chase_hip_trsm_right_upper(ctx_, CP, (int)m_, n, dA_, (long)n, dV1_, (long)m_), "trsm");
+        }
+        return info;
+    }
+
+    // Householder fallback: gather the full N x nevex block inside the column group, factor it redundantly with the
+    // single-GPU blocked Householder kernel set, keep the local rows.
+    void householder()
+    {
+        last_qr_variant_ = 0;
+        T* full = nullptr;
+        int rc = chase_hip_malloc(ctx_, (void**)&full, N_ * nevex_ * sizeof(T));
+        if (rc) throw HipStatusError(rc, "householder workspace");
+        try {
+            for (int ip = 0; ip < nprow_; ++ip) {
+                const int cnt = rowmap_cnt_[ip];
+                if (cnt == 0) continue;
+                if (ip == myrow_)
+                    hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)nevex_, dV1_, (long)m_, dStage_, (long)m_), "lacpy");
+                coll(chase_hip_grid_bcast(grid_, CHASE_HIP_COL, dStage_, (std::size_t)cnt * nevex_ * E, ip, 0));
+                hip_ok(chase_hip_rows_indexed(ctx_, CP, dStage_, cnt, full, (long)N_, d_rowmap_[ip], cnt, (int)nevex_, 1), "scatter");
+            }
+            hip_ok(chase_hip_houseqr(ctx_, CP, (int)N_, (int)nevex_, full, (long)N_), "houseqr");
+            hip_ok(chase_hip_rows_indexed(ctx_, CP, full, (long)N_, dV1_, (long)m_, d_rowmap_[myrow_], (int)m_, (int)nevex_, 0), "gather");
+            hip_ok(chase_hip_ctx_sync(ctx_), "sync");
+        } catch (...) { chase_hip_free(ctx_, full); throw; }
+        chase_hip_free(ctx_, full);
+    }
+
+    void reset_perm() { for (std::size_t i = 0; i < nevex_; ++i) perm_[i] = (int)i; perm_dirty_ = false; }
+    // apply the deferred swaps to V1 and V2 (distMultiVector.hpp:1493 swap_ij acts on both, pchase_cpu.hpp Swap)
+    void flush_swaps()
+    {
+        if (!perm_dirty_) return;
+        sync_comm();
+        std::vector<int> src, dst;
+        for (std::size_t j = 0; j < nevex_; ++j)
+            if (perm_[j] != (int)j) { src.push_back(perm_[j]); dst.push_back((int)j); }
+        if (!src.empty()) {
+            hip_ok(chase_hip_permute_cols(ctx_, CP, (int)m_, dV1_, (long)m_, dVt_, (long)m_, src.data(), dst.data(), (int)src.size()), "permute");
+            hip_ok(chase_hip_permute_cols(ctx_, CP, (int)m_, dV2_, (long)m_, dVt_, (long)m_, src.data(), dst.data(), (int)src.size()), "permute");
+        }
+        reset_perm();
+    }
+
+    // sums of `cnt` device doubles over the column group (dot products / squared norms of column-type vectors)
+    void colgroup_sum(double* d, std::size_t cnt) { coll(chase_hip_grid_allreduce(grid_, CHASE_HIP_COL, d, cnt, 0)); }
+
+    void lanczos_core(std::size_t M, std::size_t nv, bool store, R* upperb, R* theta, R* Tau, R* ritzV)
+    {
+        flush_swaps(); sync_comm();
+        T *v0, *v1, *v2, *vw;
+        double *d_alpha, *d_beta, *d_tmp;
+        void* blk = nullptr;
+        const std::size_t vec_bytes = (3 * m_ + n_) * nv * sizeof(T);
+        const std::size_t sc_bytes = (M * nv * E + M * nv + 2 * nv) * sizeof(double);
+        int rc = chase_hip_malloc(ctx_, &blk, vec_bytes + sc_bytes);
+        if (rc) throw HipStatusError(rc, "lanczos workspace");
+        v0 = (T*)blk; v1 = v0 + m_ * nv; v2 = v1 + m_ * nv; vw = v2 + m_ * nv;
+        d_alpha = (double*)(vw + n_ * nv); d_beta = d_alpha + M * nv * E; d_tmp = d_beta + M * nv;
+        const int ml = (int)m_, nvi = (int)nv;
+        try {
+            hip_ok(chase_hip_memset(ctx_, blk, 0, vec_bytes + sc_bytes), "memset");
+            hip_ok(chase_hip_lacpy(ctx_, CP, ml, nvi, dV1_, (long)m_, v1, (long)m_), "lacpy");
+            // ||v1||: local sums of squares, all-reduce over the column group, sqrt
+            sq_norms(v1, nv, d_tmp);
+            hip_ok(chase_hip_col_scal(ctx_, CP, ml, nvi, d_tmp, 1, v1, (long)m_), "scal");
+            for (std::size_t k = 0; k < M; ++k) {
+                if (store)
+                    hip_ok(chase_hip_lacpy(ctx_, CP, ml, 1, v1 + (nv - 1) * m_, (long)m_, dV1_ + k * m_, (long)m_), "lacpy");
+                // v_w = H^H v1 (row-type) + all-reduce; v2 = redistribute(v_w)
+                gemm('C', n_, nv, m_, T(1), dH_, ldh_, v1, m_, T(0), vw, n_);
+                coll(chase_hip_grid_allreduce(grid_, CHASE_HIP_COL, vw, n_ * nv * E, 0));
+                redistribute_r2c(vw, v2, nv);
+                double* ak = d_alpha + k * nv * E;
+                hip_ok(chase_hip_col_dot(ctx_, CP, ml, nvi, v1, (long)m_, v2, (long)m_, ak), "dot");
+                colgroup_sum(ak, nv * E);
+                hip_ok(chase_hip_col_axpy(ctx_, CP, ml, nvi, ak, 0, 1, -1.0, v1, (long)m_, v2, (long)m_), "axpy");
+                if (k > 0)
+                    hip_ok(chase_hip_col_axpy(ctx_, CP, ml, nvi, d_beta + (k - 1) * nv, 1, 1, -1.0, v0, (long)m_, v2, (long)m_), "axpy");
+                sq_norms(v2, nv, d_beta + k * nv);
+                if (k == M - 1) break;
+                hip_ok(chase_hip_col_scal(ctx_, CP, ml, nvi, d_beta + k * nv, 1, v2, (long)m_), "scal");
+                T* t = v0; v0 = v1; v1 = v2; v2 = t;
+            }
+            if (store) hip_ok(chase_hip_lacpy(ctx_, CP, ml, nvi, v1, (long)m_, dV1_, (long)m_), "lacpy");
+            std::vector<double> h_alpha(M * nv * E), h_beta(M * nv);
+            hip_ok(chase_hip_memcpy_d2h(ctx_, h_alpha.data(), d_alpha, h_alpha.size() * sizeof(double)), "d2h");
+            hip_ok(chase_hip_memcpy_d2h(ctx_, h_beta.data(), d_beta, h_beta.size() * sizeof(double)), "d2h");
+            chase_hip_free(ctx_, blk);
+            blk = nullptr;
+            std::vector<double> d(M), e(M), w(M), Z(M * M);
+            R ub = 0;
+            for (std::size_t i = 0; i < nv; ++i) {
+                for (std::size_t k = 0; k < M; ++k) {
+                    d[k] = h_alpha[(k * nv + i) * E];
+                    e[k] = (k + 1 < M) ? h_beta[k * nv + i] : 0.0;
+                }
+                hip_ok(chase_hip_stemr_host((int)M, d.data(), e.data(), w.data(), Z.data(), (int)M), "stemr");
+                for (std::size_t k = 0; k < M; ++k) {
+                    theta[k + i * M] = w[k];
+                    if (Tau) Tau[k + i * M] = std::abs(Z[k * M]) * std::abs(Z[k * M]);
+                }
+                if (ritzV) std::memcpy(ritzV, Z.data(), M * M * sizeof(double));
+                const R cand = std::max(std::abs(w[0]), std::abs(w[M - 1])) + std::abs(h_beta[(M - 1) * nv + i]);
+                ub = (i == 0) ? cand : std::max(ub, cand);
+            }
+            // identical bounds / Ritz data on every rank (they steer the whole iteration)
+            std::vector<R> pack;
+            pack.push_back(ub);
+            pack.insert(pack.end(), theta, theta + M * nv);
+            if (Tau) pack.insert(pack.end(), Tau, Tau + M * nv);
+            if (ritzV) pack.insert(pack.end(), ritzV, ritzV + M * M);
+            agree_vector(pack.data(), pack.size(), nullptr, 0);
+            std::size_t o = 0;
+            ub = pack[o++];
+            std::memcpy(theta, pack.data() + o, M * nv * sizeof(R)); o += M * nv;
+            if (Tau) { std::memcpy(Tau, pack.data() + o, M * nv * sizeof(R)); o += M * nv; }
+            if (ritzV) std::memcpy(ritzV, pack.data() + o, M * M * sizeof(R));
+            *upperb = ub;
+        } catch (...) {
+            if (blk) chase_hip_free(ctx_, blk);
+            throw;
+        }
+    }
+    // out[j] = ||x_j||_2 of column-type vectors: local sum of squares, column-group all-reduce, sqrt (all on device)
+    void sq_norms(const T* x, std::size_t nv, double* out)
+    {
+        hip_ok(chase_hip_col_sumsq(ctx_, CP, (int)m_, (int)nv, x, (long)m_, out), "sumsq");
+        colgroup_sum(out, nv);
+        hip_ok(chase_hip_sqrt_inplace(ctx_, out, (int)nv), "sqrt");
+    }
+
+    chase_hip_ctx* ctx_;
+    chase_hip_grid* grid_;
+    std::size_t N_, nev_, nex_, nevex_;
+    T* dH_; std::size_t ldh_;
+    R* ritzv_;
+    ConfigT config_;
+    std::vector<R> resid_, early_;
+    std::vector<int> perm_;
+    bool perm_dirty_ = false;
+    int nprow_ = 1, npcol_ = 1, myrow_ = 0, mycol_ = 0;
+    Dim Rr_, Cc_;
+    std::size_t m_ = 0, n_ = 0;
+    std::size_t locked_ = 0, lanczosIter_ = 0, numLanczos_ = 0;
+    bool next_bAc_ = true, device_rng_ = false, pipeline_ = true;
+    T *dV1_ = nullptr, *dV2_ = nullptr, *dVt_ = nullptr, *dW1_ = nullptr, *dW2_ = nullptr, *dA_ = nullptr;
+    T *dPack_ = nullptr, *dStage_ = nullptr;
+    std::size_t pack_elems_ = 0;
+    int *d_diag_rows_ = nullptr, *d_diag_cols_ = nullptr;
+    std::size_t diag_cnt_ = 0;
+    std::vector<Xfer> c2r_, r2c_;
+    std::vector<int*> d_rowmap_;
+    std::vector<int> rowmap_cnt_;
+    std::vector<void*> owned_;
+    double filter_ms_ = 0;
+    std::size_t hemm_calls_ = 0;
+    int last_qr_variant_ = 0;
+};
+
+} // namespace chase_amd

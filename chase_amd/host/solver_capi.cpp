@@ -7,16 +7,22 @@
 #include <string>
 #include "../../include/chase_hip.h"
 #include "../../include/chase_hip_solver.h"
+#include "../../include/chase_hip_grid.h"
 #include "algorithm.hpp"
 #include "chase_hip_impl.hpp"
+#include "pchase_hip_impl.hpp"
 
 namespace chase_hip { int set_error(int code, const char* what); }
 using namespace chase_amd;
 
+using zc = std::complex<double>;
 struct chase_hip_solver {
     int cplx = 0;
-    std::unique_ptr<ChaseHip<double>> d;
-    std::unique_ptr<ChaseHip<std::complex<double>>> z;
+    std::unique_ptr<ChaseBase<double>> d;           // ChaseHip<double> or pChaseHip<double>
+    std::unique_ptr<ChaseBase<zc>> z;
+    HipImplExtras* ex = nullptr;                    // same object, Impl-specific extras
+    pChaseHip<double>* pd = nullptr;                // set for the distributed Impl only
+    pChaseHip<zc>* pz = nullptr;
     SolveStats stats;
     CallTrace trace;
     std::string trace_text;
@@ -53,16 +59,62 @@ int chase_hip_solver_create(chase_hip_solver** out, chase_hip_ctx* ctx, int cplx
     auto s = std::make_unique<chase_hip_solver>();
     s->cplx = cplx ? 1 : 0;
     int rc = guarded("solver_create", [&] {
-        if (cplx)
-            s->z = std::make_unique<ChaseHip<std::complex<double>>>(ctx, N, nev, nex, (std::complex<double>*)H, ldh,
-                                                                    (std::complex<double>*)V, ldv, ritzv,
-                                                                    h_on_device != 0);
-        else
-            s->d = std::make_unique<ChaseHip<double>>(ctx, N, nev, nex, (double*)H, ldh, (double*)V, ldv, ritzv,
-                                                      h_on_device != 0);
+        if (cplx) {
+            auto* p = new ChaseHip<zc>(ctx, N, nev, nex, (zc*)H, ldh, (zc*)V, ldv, ritzv, h_on_device != 0);
+            s->z.reset(p); s->ex = p;
+        } else {
+            auto* p = new ChaseHip<double>(ctx, N, nev, nex, (double*)H, ldh, (double*)V, ldv, ritzv, h_on_device != 0);
+            s->d.reset(p); s->ex = p;
+        }
     });
     if (rc) return rc;
     *out = s.release();
+    return 0;
+}
+
+int chase_hip_psolver_create(chase_hip_solver** out, chase_hip_ctx* ctx, chase_hip_grid* grid, int cplx, size_t N,
+                             size_t nev, size_t nex, size_t mb, size_t nb, void* H_loc_dev, size_t ldh, double* ritzv)
+{
+    if (!out || !ctx || !grid || !H_loc_dev || !ritzv)
+        return chase_hip::set_error(CHASE_HIP_EINVAL, "psolver_create: NULL argument");
+    auto s = std::make_unique<chase_hip_solver>();
+    s->cplx = cplx ? 1 : 0;
+    int rc = guarded("psolver_create", [&] {
+        if (cplx) {
+            auto* p = new pChaseHip<zc>(ctx, grid, N, nev, nex, mb, nb, (zc*)H_loc_dev, ldh, ritzv);
+            s->z.reset(p); s->ex = p; s->pz = p;
+        } else {
+            auto* p = new pChaseHip<double>(ctx, grid, N, nev, nex, mb, nb, (double*)H_loc_dev, ldh, ritzv);
+            s->d.reset(p); s->ex = p; s->pd = p;
+        }
+    });
+    if (rc) return rc;
+    *out = s.release();
+    return 0;
+}
+
+/* local shape of the distributed solver's blocks: rows of V (== rows of H_loc) and columns of H_loc */
+int chase_hip_psolver_local_shape(chase_hip_solver* s, size_t* m_loc, size_t* n_loc)
+{
+    if (!s || (!s->pd && !s->pz)) return chase_hip::set_error(CHASE_HIP_EINVAL, "not a distributed solver");
+    if (m_loc) *m_loc = s->ex->local_rows();
+    if (n_loc) *n_loc = s->pz ? s->pz->local_cols_h() : s->pd->local_cols_h();
+    return 0;
+}
+int chase_hip_psolver_upload_v(chase_hip_solver* s, const void* host, size_t ldv)
+{
+    if (!s || (!s->pd && !s->pz)) return chase_hip::set_error(CHASE_HIP_EINVAL, "not a distributed solver");
+    return guarded("upload_v", [&] { if (s->pz) s->pz->upload_local_V((const zc*)host, ldv); else s->pd->upload_local_V((const double*)host, ldv); });
+}
+int chase_hip_psolver_download_v(chase_hip_solver* s, void* host, size_t ldv)
+{
+    if (!s || (!s->pd && !s->pz)) return chase_hip::set_error(CHASE_HIP_EINVAL, "not a distributed solver");
+    return guarded("download_v", [&] { if (s->pz) s->pz->download_local_V((zc*)host, ldv); else s->pd->download_local_V((double*)host, ldv); });
+}
+int chase_hip_psolver_set_pipeline(chase_hip_solver* s, int on)
+{
+    if (!s || (!s->pd && !s->pz)) return chase_hip::set_error(CHASE_HIP_EINVAL, "not a distributed solver");
+    if (s->pz) s->pz->set_pipeline(on != 0); else s->pd->set_pipeline(on != 0);
     return 0;
 }
 
@@ -90,8 +142,8 @@ int chase_hip_solver_set(chase_hip_solver* s, const char* key, double v)
         else if (name == "approx") c.SetApprox(v != 0);
         else if (name == "cholqr") c.SetCholQR(v != 0);
         else if (name == "decayingrate") c.SetDecayingRate((float)v);
-        else if (name == "device_rng") k.set_device_rng(v != 0);
-        else if (name == "reset_counters") k.reset_counters();
+        else if (name == "device_rng") s->ex->set_device_rng(v != 0);
+        else if (name == "reset_counters") s->ex->reset_counters();
         else rc = chase_hip::set_error(CHASE_HIP_EINVAL, "solver_set: unknown key");
     });
     return rc;
@@ -115,10 +167,10 @@ int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* out)
         else if (name == "approx") *out = c.UseApprox();
         else if (name == "cholqr") *out = c.DoCholQR();
         else if (name == "decayingrate") *out = c.GetDecayingRate();
-        else if (name == "locked") *out = (double)k.locked();
-        else if (name == "qr_variant") *out = (double)k.last_qr_variant();
-        else if (name == "filter_ms") *out = k.filter_ms();
-        else if (name == "hemm_calls") *out = (double)k.hemm_calls();
+        else if (name == "locked") *out = (double)s->ex->locked();
+        else if (name == "qr_variant") *out = (double)s->ex->last_qr_variant();
+        else if (name == "filter_ms") *out = s->ex->filter_ms();
+        else if (name == "hemm_calls") *out = (double)s->ex->hemm_calls();
         else rc = chase_hip::set_error(CHASE_HIP_EINVAL, "solver_get: unknown key");
     });
     return rc;
@@ -131,8 +183,8 @@ int chase_hip_solver_solve(chase_hip_solver* s, int record_trace)
     s->trace.lines.clear();
     s->trace.enabled = record_trace != 0;
     return guarded("solve", [&] {
-        if (s->cplx) Algorithm<std::complex<double>, ChaseHip<std::complex<double>>>::solve(s->z.get(), &s->stats, &s->trace);
-        else Algorithm<double, ChaseHip<double>>::solve(s->d.get(), &s->stats, &s->trace);
+        if (s->cplx) Algorithm<zc, ChaseBase<zc>>::solve(s->z.get(), &s->stats, &s->trace);
+        else Algorithm<double, ChaseBase<double>>::solve(s->d.get(), &s->stats, &s->trace);
     });
 }
 
@@ -228,8 +280,9 @@ int chase_hip_op_check_symmetry(chase_hip_solver* s, int* is_sym)
 int chase_hip_solver_peek_v(chase_hip_solver* s, chase_hip_ctx* ctx, void* host, size_t ldh)
 {
     return guarded("peek_v", [&] {
-        DISPATCH(s, hip_ok(chase_hip_download_matrix(ctx, s->cplx, (int)k.GetN(), (int)k.GetRitzvBlockSize(),
-                                                     k.device_V1(), (long)k.GetN(), host, (long)ldh), "download"));
+        DISPATCH(s, hip_ok(chase_hip_download_matrix(ctx, s->cplx, (int)s->ex->local_rows(), (int)k.GetRitzvBlockSize(),
+                                                     s->ex->device_V1(), (long)s->ex->local_rows(), host, (long)ldh),
+                           "download"));
     });
 }
 

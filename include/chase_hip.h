@@ -78,6 +78,12 @@ int chase_hip_ctx_set_phase(chase_hip_ctx* ctx, int phase);
 /* N(0,1) fill (Philox4x32-10 + Box-Muller).  Replaces cuda/random_normal_distribution.cu:21-95 (initVecs on GPU) */
 int chase_hip_fill_normal(chase_hip_ctx* ctx, int cplx, int m, int n, void* X, long ldx, long grow0, long gcol0,
                           long gld, unsigned long long seed);
+int chase_hip_fill_normal_bc(chase_hip_ctx* ctx, int cplx, int m, int n, void* X, long ldx, long gld, int mb, int pr,
+                             int pi, unsigned long long seed);
+/* row gather / scatter by a device index list (column-type <-> row-type multivector redistribution,
+ * linalg/distMatrix/distMultiVector.hpp:2444-2720) */
+int chase_hip_rows_indexed(chase_hip_ctx* ctx, int cplx, const void* in, long ld_in, void* out, long ld_out,
+                           const int* idx_dev, int np, int ncols, int scatter);
 /* Clement-type test matrix of the reference's solve tests (tests/chase_serial_solve.cpp:52-90), any 2D shard:
  * H = scale * (Clement + perturb * G), G dense Hermitian N(0,1) on the entries the reference perturbs */
 int chase_hip_gen_clement(chase_hip_ctx* ctx, int cplx, void* H, long ldh, int mloc, int nloc, long N, int mb, int pr,
@@ -132,6 +138,7 @@ int chase_hip_houseqr(chase_hip_ctx* ctx, int cplx, int m, int n, void* V, long 
 
 /* ---- Rayleigh-Ritz: host HEEVD of a device matrix ('V','L'), eigenvectors back on the device -------------------- */
 int chase_hip_heevd(chase_hip_ctx* ctx, int cplx, int n, void* A, long lda, double* w_host);
+int chase_hip_heevd_host(int cplx, int n, void* A_host, long lda, double* w_host); /* host-only twin (provider check) */
 /* host-only: all eigenpairs of a symmetric tridiagonal (Lanczos; lapackpp::t_stemr, cpu/lanczos.hpp:188) */
 int chase_hip_stemr_host(int n, double* d, double* e, double* w, double* Z, int ldz);
 
@@ -140,6 +147,9 @@ int chase_hip_stemr_host(int n, double* d, double* e, double* w, double* Z, int 
 int chase_hip_col_dot(chase_hip_ctx* ctx, int cplx, int m, int n, const void* X, long ldx, const void* Y, long ldy,
                       double* out_dev);
 int chase_hip_col_nrm2(chase_hip_ctx* ctx, int cplx, int m, int n, const void* X, long ldx, double* out_dev);
+/* partial sums of squares + elementwise sqrt (distributed norms: cuda/lanczos_kernels.cu:433-441 batched_sqrt) */
+int chase_hip_col_sumsq(chase_hip_ctx* ctx, int cplx, int m, int n, const void* X, long ldx, double* out_dev);
+int chase_hip_sqrt_inplace(chase_hip_ctx* ctx, double* x_dev, int n);
 /* Y_j += sgn * a[j*a_stride] * X_j; a is a device array of reals (a_is_real) or of T */
 int chase_hip_col_axpy(chase_hip_ctx* ctx, int cplx, int m, int n, const double* a_dev, int a_is_real, int a_stride,
                        double sgn, const void* X, long ldx, void* Y, long ldy);

@@ -1,0 +1,61 @@
+/* chase_hip_grid.h — C ABI of the 2D process grid and its collectives (one process per GPU).
+ *
+ * Replaces grid/mpiGrid2D.hpp (MpiGrid2D<ColMajor>: Cartesian grid, row/col communicators, three ncclComm_t) and the
+ * typed wrappers of grid/nccl_utils.hpp:200-278.  Rank -> coordinates is the reference's column-major grid ordering
+ * (rank = row + col * nprow, grid/mpiGrid2D.hpp:402-446).  Two transports:
+ *   - RCCL over xGMI (production): ncclAllReduce / ncclBroadcast of doubles on a dedicated HIP stream;
+ *   - host callbacks (test plumbing): the payload is staged through pinned host memory and handed to a callback
+ *     (tests supply torch.distributed/gloo), which lets N ranks share ONE GPU so that the distributed code path is
+ *     exercised on a single-GPU box.
+ * Groups: CHASE_HIP_ROW = ranks sharing a grid row (size npcol, the reference's row_comm),
+ *         CHASE_HIP_COL = ranks sharing a grid column (size nprow, the reference's col_comm).
+ * Data layout helpers implement the reference's block rule (linalg/distMatrix/distMatrix.hpp:1992-2052) and numroc
+ * (:44-67); a block layout is the block-cyclic layout with block size = block length. */
+#ifndef CHASE_HIP_GRID_H
+#define CHASE_HIP_GRID_H
+#include <stddef.h>
+#include "chase_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHASE_HIP_ROW 0
+#define CHASE_HIP_COL 1
+#define CHASE_HIP_UNIQUE_ID_BYTES 128
+
+typedef struct chase_hip_grid chase_hip_grid;
+typedef int (*chase_hip_host_allreduce_fn)(void* user, int group, double* buf, size_t count);
+typedef int (*chase_hip_host_bcast_fn)(void* user, int group, double* buf, size_t count, int root);
+
+int chase_hip_rccl_unique_id(char id[CHASE_HIP_UNIQUE_ID_BYTES]);
+/* id_row / id_col: the unique ids of THIS rank's row group and column group (ignored when that group has size 1) */
+int chase_hip_grid_create_rccl(chase_hip_grid** out, chase_hip_ctx* ctx, int nprow, int npcol, int rank,
+                               const char id_row[CHASE_HIP_UNIQUE_ID_BYTES],
+                               const char id_col[CHASE_HIP_UNIQUE_ID_BYTES]);
+int chase_hip_grid_create_host(chase_hip_grid** out, chase_hip_ctx* ctx, int nprow, int npcol, int rank,
+                               chase_hip_host_allreduce_fn allreduce, chase_hip_host_bcast_fn bcast, void* user);
+int chase_hip_grid_destroy(chase_hip_grid* g);
+int chase_hip_grid_info(chase_hip_grid* g, int* nprow, int* npcol, int* myrow, int* mycol);
+/* in-place SUM all-reduce / broadcast of `count` doubles of device memory inside `group`; ordered after the work
+ * already enqueued on the context stream, and the context stream waits for the result (async = 0), or the caller
+ * orders it with chase_hip_grid_wait (async != 0: the collective runs on the grid's communication stream). */
+int chase_hip_grid_allreduce(chase_hip_grid* g, int group, void* dev, size_t count, int async);
+int chase_hip_grid_bcast(chase_hip_grid* g, int group, void* dev, size_t count, int root, int async);
+int chase_hip_grid_wait(chase_hip_grid* g); /* context stream waits for all collectives issued so far */
+/* per-slot events for pipelining: record on the communication stream / make the context stream wait for a slot */
+int chase_hip_grid_event_record(chase_hip_grid* g, int slot);
+int chase_hip_grid_event_wait(chase_hip_grid* g, int slot);
+/* all ranks agree on the maximum of a host integer (control-flow decisions such as the potrf info) */
+int chase_hip_grid_agree_max(chase_hip_grid* g, int* value);
+
+/* ---- layout helpers (pure host arithmetic, no GPU needed) ------------------------------------------------------ */
+long chase_hip_block_len(long n, int nprocs);                      /* distMatrix.hpp:2000-2007 */
+long chase_hip_numroc(long n, long nb, int iproc, int nprocs);     /* distMatrix.hpp:44-67 (isrcproc = 0) */
+int chase_hip_owner(long g, long nb, int nprocs);                  /* (g / nb) % nprocs */
+long chase_hip_local_index(long g, long nb, int nprocs);           /* (g / (nb*nprocs)) * nb + g % nb */
+long chase_hip_global_index(long l, long nb, int iproc, int nprocs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

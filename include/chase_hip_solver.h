@@ -9,6 +9,7 @@
 #define CHASE_HIP_SOLVER_H
 #include <stddef.h>
 #include "chase_hip.h"
+#include "chase_hip_grid.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -27,6 +28,16 @@ typedef struct chase_hip_stats {
  * h_on_device != 0 declares H a device pointer that is used in place. */
 int chase_hip_solver_create(chase_hip_solver** out, chase_hip_ctx* ctx, int cplx, size_t N, size_t nev, size_t nex,
                             void* H, size_t ldh, void* V, size_t ldv, double* ritzv, int h_on_device);
+/* Distributed Impl (pChASECPU / pChASEGPU constructor contract, pchase_cpu.hpp:92-93): H_loc is this rank's DEVICE
+ * block of the N x N matrix, distributed block-cyclically with (mb, nb) over the grid (mb = nb = 0: the reference's block
+ * layout); the nev+nex vectors live distributed on the devices (chase_hip_psolver_{upload,download}_v move a rank's
+ * m_loc x (nev+nex) block).  All op / solve entry points below are collective over the grid. */
+int chase_hip_psolver_create(chase_hip_solver** out, chase_hip_ctx* ctx, chase_hip_grid* grid, int cplx, size_t N,
+                             size_t nev, size_t nex, size_t mb, size_t nb, void* H_loc_dev, size_t ldh, double* ritzv);
+int chase_hip_psolver_local_shape(chase_hip_solver* s, size_t* m_loc, size_t* n_loc);
+int chase_hip_psolver_upload_v(chase_hip_solver* s, const void* host, size_t ldv);
+int chase_hip_psolver_download_v(chase_hip_solver* s, void* host, size_t ldv);
+int chase_hip_psolver_set_pipeline(chase_hip_solver* s, int on); /* 0: no compute/communication overlap (debug) */
 int chase_hip_solver_destroy(chase_hip_solver* s);
 /* keys: tol deg maxdeg degextra maxiter lanczositer numlanczos opt approx cholqr decayingrate
  * (ChaseConfig setters, algorithm/configuration.hpp:197-462); get additionally: locked qr_variant filter_ms */
