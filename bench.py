@@ -29,6 +29,8 @@ FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X fp64 matrix == vector peak (vendor fi
 MATRIX_SCALE = 100.0
 MATRIX_PERTURB = 1e-6
 
+DEFAULT_WORKLOAD = "cfg2"
+
 WORKLOADS = {
     # name: (N, complex, nev, nex)
     "cfg1": (4096, False, 100, 40),
@@ -148,6 +150,7 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="override N (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
+    ap.add_argument("--block-cyclic", type=int, default=0, help="block size of a block-cyclic H distribution (0 = block)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1:
@@ -157,7 +160,7 @@ def main():
             print(json.dumps(out), flush=True)
         return
     if args.workload is None:
-        args.workload = "cfg2"
+        args.workload = DEFAULT_WORKLOAD
     out = run_single(args)
     print(json.dumps(out), flush=True)
 
