@@ -189,7 +189,7 @@ int chase_hip_gemm_d(chase_hip_ctx* c, char opA, int m, int n, int k, double alp
     if (!c) return set_error(CHASE_HIP_EINVAL, "ctx == NULL");
     int rc = check_gemm(opA, m, n, k, A, lda, B, ldb, C, ldc);
     if (rc) return rc;
-    rc = c->ensure_ws((size_t)64 << 20);
+    rc = c->ensure_ws((size_t)640 << 20);
     if (rc) return rc;
     int e = gemm_f64(c->stream, false, opA, m, n, k, &alpha, A, lda, B, ldb, &beta, C, ldc, (double*)c->ws,
                      c->ws_bytes, c->num_cu, c->phase);
@@ -204,7 +204,7 @@ int chase_hip_gemm_z(chase_hip_ctx* c, char opA, int m, int n, int k, const doub
     if (!alpha || !beta) return set_error(CHASE_HIP_EINVAL, "gemm_z: NULL alpha/beta");
     int rc = check_gemm(opA, m, n, k, A, lda, B, ldb, C, ldc);
     if (rc) return rc;
-    rc = c->ensure_ws((size_t)64 << 20);
+    rc = c->ensure_ws((size_t)640 << 20);
     if (rc) return rc;
     int e = gemm_f64(c->stream, true, opA, m, n, k, alpha, (const double*)A, lda, (const double*)B, ldb, beta,
                      (double*)C, ldc, (double*)c->ws, c->ws_bytes, c->num_cu, c->phase);

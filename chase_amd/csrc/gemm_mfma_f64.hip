@@ -32,6 +32,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include "kernels.h"
 
 namespace chase_hip {
@@ -71,9 +72,13 @@ struct GemmArgs {
     const double* A; const double* B; double* C;     // C may point to split-K slabs
     long lda, ldb, ldc;                              // in elements of T
     int m, n, k;
-    int gm, gn, splitk, kchunk;                      // grid decomposition; kchunk multiple of BK
+    int gm, gn;                                      // output tiles
+    // Work decomposition (removes wave quantisation for arbitrary active widths): blocks [0, full_tiles) own one whole
+    // output tile each; the remaining tiles ("tail": fewer than one full round of the chip) are cut into tail_sk K pieces
+    // of tail_kchunk each, written as raw BM x BN partial slabs and combined by tail_reduce_kernel in a fixed order.
+    int full_tiles, tail_sk, tail_kchunk;
+    double* slabs;
     double alpha_re, alpha_im, beta_re, beta_im;
-    long slab_stride;                                // elements of T between split-K slabs (0 if splitk == 1)
 };
 
 // TAG only changes the symbol name: TAG = 1 is the instantiation launched between FilterPhaseStart/End, so that
@@ -94,15 +99,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
     const int c16 = lane & 15, q = lane >> 4;
 
     // ---- logical tile -------------------------------------------------------------------------------------------
-    const unsigned nblk = gridDim.x;
-    unsigned L = xcd_remap(blockIdx.x, nblk);
-    const int bn = L % p.gn; L /= p.gn;
-    const int bm = L % p.gm; L /= p.gm;
-    const int bz = L;                               // split-K slice
+    unsigned tile;
+    int kbeg = 0, kend = p.k;
+    bool raw = false;                               // true: this block produces a partial slab of a tail tile
+    double* slab = nullptr;
+    if (blockIdx.x < (unsigned)p.full_tiles) {
+        tile = xcd_remap(blockIdx.x, (unsigned)p.full_tiles);
+    } else {
+        const unsigned P = xcd_remap(blockIdx.x - (unsigned)p.full_tiles, gridDim.x - (unsigned)p.full_tiles);
+        tile = (unsigned)p.full_tiles + P / (unsigned)p.tail_sk;
+        const int bz = (int)(P % (unsigned)p.tail_sk);
+        kbeg = bz * p.tail_kchunk;
+        kend = min(p.k, kbeg + p.tail_kchunk);
+        raw = true;
+        slab = p.slabs + (size_t)P * (BM * BN * EPT);
+    }
+    const int bn = tile % p.gn, bm = tile / p.gn;
     const int row0 = bm * BM, col0 = bn * BN;
-    const int kbeg = bz * p.kchunk;
-    const int kend = min(p.k, kbeg + p.kchunk);
-    const int nkt = (kend - kbeg + BK - 1) / BK;
+    const int nkt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
 
     const bool interior = (row0 + BM <= p.m) && (col0 + BN <= p.n);
 
@@ -295,8 +309,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
 
     // ---- epilogue -----------------------------------------------------------------------------------------------
     // accumulator element: D[row = q + 4g -> N index][col = c16 -> M index]
-    double* Cb = p.C + (long)bz * p.slab_stride * EPT;
-    const bool raw = (p.splitk > 1);                 // slabs get the unscaled partial sums
+    // raw blocks store the unscaled partial tile into their slab (tile-local coordinates, ld = BM, no bounds)
+    double* Cb = raw ? slab : p.C;
+    const long ldc_e = raw ? BM : p.ldc;
+    const int srow0 = raw ? 0 : row0, scol0 = raw ? 0 : col0;
+    const int m_e = raw ? BM : p.m, n_e = raw ? BN : p.n;
     const double are = p.alpha_re, aim = p.alpha_im, bre = p.beta_re, bim = p.beta_im;
     const bool has_beta = (bre != 0.0) || (bim != 0.0);
 
@@ -304,14 +321,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
     for (int j = 0; j < TN; ++j) {
         #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int gj = col0 + wcol + 16 * j + q + 4 * g;
-            if (gj >= p.n) continue;
+            const int gj = scol0 + wcol + 16 * j + q + 4 * g;
+            if (gj >= n_e) continue;
             if constexpr (CPLX) {
                 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const int gi = row0 + wrow + 16 * i + c16;
-                    if (gi >= p.m) continue;
-                    double* c = Cb + ((long)gj * p.ldc + gi) * 2;
+                    const int gi = srow0 + wrow + 16 * i + c16;
+                    if (gi >= m_e) continue;
+                    double* c = Cb + ((long)gj * ldc_e + gi) * 2;
                     const double xr = acc[0][j][i][g], xi = acc[1][j][i][g];
                     d2_t out;
                     if (raw) { out = d2_t{xr, xi}; }
@@ -328,23 +345,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
             } else if constexpr (!OPA_C) {
                 #pragma unroll
                 for (int pr = 0; pr < TM / 2; ++pr) {
-                    const int gi = row0 + wrow + 32 * pr + 2 * c16;          // rows gi, gi+1 <- tiles 2pr, 2pr+1
-                    if (gi >= p.m) continue;
-                    double* c = Cb + (long)gj * p.ldc + gi;
+                    const int gi = srow0 + wrow + 32 * pr + 2 * c16;         // rows gi, gi+1 <- tiles 2pr, 2pr+1
+                    if (gi >= m_e) continue;
+                    double* c = Cb + (long)gj * ldc_e + gi;
                     double x0 = acc[0][j][2 * pr][g], x1 = acc[0][j][2 * pr + 1][g];
                     if (!raw) {
                         x0 *= are; x1 *= are;
-                        if (has_beta) { x0 += bre * c[0]; if (gi + 1 < p.m) x1 += bre * c[1]; }
+                        if (has_beta) { x0 += bre * c[0]; if (gi + 1 < m_e) x1 += bre * c[1]; }
                     }
-                    if (gi + 1 < p.m) *(d2u_t*)c = d2_t{x0, x1};
+                    if (gi + 1 < m_e) *(d2u_t*)c = d2_t{x0, x1};
                     else c[0] = x0;
                 }
             } else {
                 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const int gi = row0 + wrow + 16 * i + c16;
-                    if (gi >= p.m) continue;
-                    double* c = Cb + (long)gj * p.ldc + gi;
+                    const int gi = srow0 + wrow + 16 * i + c16;
+                    if (gi >= m_e) continue;
+                    double* c = Cb + (long)gj * ldc_e + gi;
                     double x0 = acc[0][j][i][g];
                     if (!raw) { x0 *= are; if (has_beta) x0 += bre * c[0]; }
                     c[0] = x0;
@@ -354,30 +371,39 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
     }
 }
 
-// C = alpha * sum_z slab_z + beta * C    (fixed summation order => bitwise reproducible)
-template <bool CPLX>
-__global__ void splitk_reduce_kernel(const double* __restrict__ slabs, long slab_stride, int splitk, int m, int n,
-                                     double* __restrict__ C, long ldc, double are, double aim, double bre, double bim)
+// tail tiles: C[tile] = alpha * sum_z slab[tile][z] + beta * C[tile]   (fixed summation order => bitwise reproducible)
+// one workgroup per tail tile; slabs are BM x BN tiles (ld = BM) in tile-local coordinates
+template <bool CPLX, int BM, int BN>
+__global__ __launch_bounds__(256) void tail_reduce_kernel(const double* __restrict__ slabs, int first_tile, int sk,
+                                                          int gn, int m, int n, double* __restrict__ C, long ldc,
+                                                          double are, double aim, double bre, double bim)
 {
-    const long total = (long)m * n;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int i = (int)(e % m), j = (int)(e / m);
+    constexpr int EPT = CPLX ? 2 : 1;
+    const int tt = blockIdx.x;
+    const int tile = first_tile + tt;
+    const int row0 = (tile / gn) * BM, col0 = (tile % gn) * BN;
+    const double* base = slabs + (size_t)tt * sk * (BM * BN * EPT);
+    const bool has_beta = (bre != 0.0) || (bim != 0.0);
+    for (int e = threadIdx.x; e < BM * BN; e += 256) {
+        const int li = e % BM, lj = e / BM;
+        const int gi = row0 + li, gj = col0 + lj;
+        if (gi >= m || gj >= n) continue;
         if constexpr (CPLX) {
             double sr = 0.0, si = 0.0;
-            for (int z = 0; z < splitk; ++z) {
-                const d2_t v = *(const d2_t*)(slabs + ((long)z * slab_stride + e) * 2);
+            for (int z = 0; z < sk; ++z) {
+                const d2_t v = *(const d2_t*)(base + ((size_t)z * BM * BN + e) * 2);
                 sr += v.x; si += v.y;
             }
-            double* c = C + ((long)j * ldc + i) * 2;
+            double* c = C + ((long)gj * ldc + gi) * 2;
             double orr = are * sr - aim * si, oi = are * si + aim * sr;
-            if (bre != 0.0 || bim != 0.0) { const double cr = c[0], ci = c[1]; orr += bre * cr - bim * ci; oi += bre * ci + bim * cr; }
+            if (has_beta) { const double cr = c[0], ci = c[1]; orr += bre * cr - bim * ci; oi += bre * ci + bim * cr; }
             c[0] = orr; c[1] = oi;
         } else {
-            double s = 0.0;
-            for (int z = 0; z < splitk; ++z) s += slabs[(long)z * slab_stride + e];
-            double* c = C + (long)j * ldc + i;
-            double o = are * s;
-            if (bre != 0.0) o += bre * c[0];
+            double sum = 0.0;
+            for (int z = 0; z < sk; ++z) sum += base[(size_t)z * BM * BN + e];
+            double* c = C + (long)gj * ldc + gi;
+            double o = are * sum;
+            if (has_beta) o += bre * c[0];
             c[0] = o;
         }
     }
@@ -395,26 +421,26 @@ static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha,
     a.gm = (m + C_::BM - 1) / C_::BM; a.gn = (n + C_::BN - 1) / C_::BN;
     a.alpha_re = alpha[0]; a.alpha_im = CPLX ? alpha[1] : 0.0;
     a.beta_re = beta[0];   a.beta_im = CPLX ? beta[1] : 0.0;
-    // split-K when the output grid cannot fill the chip (Gram-type products: k = N >> m, n)
     const long tiles = (long)a.gm * a.gn;
+    const long slots = 2L * num_cu;                          // two workgroups per CU
     const int nkt = (k + C_::BK - 1) / C_::BK;
-    int splitk = 1;
-    const long target = 2L * num_cu;
-    if (tiles < target && nkt >= 16 && ws != nullptr) {
-        splitk = (int)((target + tiles - 1) / tiles);
-        if (splitk > nkt / 8) splitk = nkt / 8;           // keep >= 8 K steps per slice
-        if (splitk > 64) splitk = 64;
-        const size_t slab_bytes = (size_t)m * n * sizeof(double) * C_::EPT;
-        while (splitk > 1 && slab_bytes * splitk > ws_bytes) --splitk;
-        if (splitk < 1) splitk = 1;
+    long full = (tiles / slots) * slots;
+    long tail = tiles - full;
+    int sk = 1;
+    const size_t slab_bytes = (size_t)C_::BM * C_::BN * sizeof(double) * C_::EPT;
+    if (tail > 0 && ws != nullptr && nkt >= 16) {
+        // cost of the tail in units of "one tile on one slot": ceil(tail*sk/slots)/sk rounds, slightly penalising big sk
+        const int sk_max = (int)std::min<long>(std::min<long>(64, nkt / 8), (long)(ws_bytes / (slab_bytes * (size_t)tail)));
+        double best = 1e30;
+        for (int c = 1; c <= sk_max; ++c) {
+            const double rounds = (double)((tail * c + slots - 1) / slots) / c + 0.004 * c;
+            if (rounds < best - 1e-12) { best = rounds; sk = c; }
+        }
     }
-    int kchunk = ((nkt + splitk - 1) / splitk) * C_::BK;
-    if (kchunk <= 0) kchunk = C_::BK;
-    splitk = (k + kchunk - 1) / kchunk; if (splitk < 1) splitk = 1;
-    a.splitk = splitk; a.kchunk = kchunk;
-    a.slab_stride = 0;
-    if (splitk > 1) { a.C = ws; a.ldc = m; a.slab_stride = (long)m * n; }
-    const unsigned grid = (unsigned)(tiles * splitk);
+    if (sk <= 1) { full = tiles; tail = 0; sk = 1; }         // nothing to split: every tile is a whole tile
+    int kchunk = ((nkt + sk - 1) / sk) * C_::BK;
+    a.full_tiles = (int)full; a.tail_sk = sk; a.tail_kchunk = kchunk; a.slabs = ws;
+    const unsigned grid = (unsigned)(full + tail * sk);
     const size_t lds_bytes = 2 * C_::STAGE_UNITS * sizeof(d2_t);
     static bool attr_set = false;
     if (!attr_set) {
@@ -422,11 +448,9 @@ static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha,
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG>), dim3(grid), dim3(256), lds_bytes, st, a);
-    if (splitk > 1) {
-        const long total = (long)m * n;
-        unsigned rb = (unsigned)((total + 255) / 256); if (rb > 4096) rb = 4096;
-        hipLaunchKernelGGL((splitk_reduce_kernel<CPLX>), dim3(rb), dim3(256), 0, st, ws, (long)m * n, splitk, m, n,
-                           C, ldc, a.alpha_re, a.alpha_im, a.beta_re, a.beta_im);
+    if (tail > 0) {
+        hipLaunchKernelGGL((tail_reduce_kernel<CPLX, C_::BM, C_::BN>), dim3((unsigned)tail), dim3(256), 0, st, ws,
+                           (int)full, sk, a.gn, m, n, C, ldc, a.alpha_re, a.alpha_im, a.beta_re, a.beta_im);
     }
     return (int)hipGetLastError();
 }

@@ -214,7 +214,7 @@ extern "C" int chase_hip_houseqr(chase_hip_ctx* c, int cplx_, int m, int n, void
     double* A = (double*)V_;
     hipStream_t st = c->stream;
     const int npan = (n + HNB - 1) / HNB;
-    RC(c->ensure_ws((size_t)64 << 20));
+    RC(c->ensure_ws((size_t)640 << 20));
     // one scratch block: Q (m x n) | Vb (m x nb) | W1, W2 (nb x n) | G (nb x nb) | T (npan x nb x nb) | tau (n)
     const size_t szQ = (size_t)m * n * E, szV = (size_t)m * HNB * E, szW = (size_t)HNB * n * E;
     const size_t szG = (size_t)HNB * HNB * E, szT = (size_t)npan * HNB * HNB * E, szTau = (size_t)n * E;
