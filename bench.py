@@ -30,6 +30,10 @@ MATRIX_SCALE = 100.0
 MATRIX_PERTURB = 1e-6
 
 DEFAULT_WORKLOAD = "cfg2"
+# BASELINE.json assigns one configuration to each GPU count (configs[1] 1 GPU, configs[2] 4 GPUs, configs[3] 8 GPUs);
+# 2 GPUs run configs[2] on a 2x1 grid.  --workload overrides (e.g. cfg4 on every N for a strong-scaling series).
+DEFAULT_BY_GPUS = {1: "cfg2", 2: "cfg3", 4: "cfg3", 8: "cfg4"}
+DEFAULT_BLOCK_CYCLIC = {"cfg4": 64}          # BASELINE configs[3]: block-cyclic distribution (nb = 64, examples/1_hello_world)
 
 WORKLOADS = {
     # name: (N, complex, nev, nex)
@@ -150,7 +154,8 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="override N (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
-    ap.add_argument("--block-cyclic", type=int, default=0, help="block size of a block-cyclic H distribution (0 = block)")
+    ap.add_argument("--block-cyclic", type=int, default=-1,
+                    help="block size of a block-cyclic H distribution (0 = block layout, -1 = the workload's default)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1:

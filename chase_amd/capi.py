@@ -217,6 +217,7 @@ _sig("chase_hip_trsm_right_upper", c_int, c_void_p, c_int, c_int, c_int, c_void_
 _sig("chase_hip_cholqr", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_long)
 _sig("chase_hip_houseqr", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long)
 _sig("chase_hip_heevd", c_int, c_void_p, c_int, c_int, c_void_p, c_long, c_void_p)
+_sig("chase_hip_heevd_gpu", c_int, c_void_p, c_int, c_int, c_void_p, c_long, c_void_p)
 _sig("chase_hip_heevd_host", c_int, c_int, c_int, c_void_p, c_long, c_void_p)
 _sig("chase_hip_stemr_host", c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int)
 _sig("chase_hip_col_dot", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p)

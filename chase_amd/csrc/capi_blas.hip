@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -355,11 +356,19 @@ int chase_hip_resid_norms(chase_hip_ctx* c, int cplx, int m, int n, const void* 
 /* Hermitian eigendecomposition of the device matrix A (n x n, lower triangle referenced) on the HOST
  * (north star: "small HEEV on host"; reference lapackpp::t_heevd 'V','L').  Eigenvalues ascending to w_host,
  * eigenvectors overwrite A on the device. */
+extern "C" int chase_hip_heevd_gpu(chase_hip_ctx* c, int cplx, int n, void* A, long lda, double* w_host);
+
 int chase_hip_heevd(chase_hip_ctx* c, int cplx, int n, void* A, long lda, double* w_host)
 {
     if (!c || !w_host) return set_error(CHASE_HIP_EINVAL, "heevd: NULL argument");
     if (n < 0 || lda < n) return set_error(CHASE_HIP_EINVAL, "heevd: bad shape");
     if (n == 0) return 0;
+    {   // large projected problems: tridiagonalise and back-transform on the GPU, only the O(n^2) tridiagonal solve on
+        // the host (hetrd.hip).  CHASE_HIP_HEEVD_GPU_MIN overrides the switch-over size (0 = always host).
+        static int thr = -1;
+        if (thr < 0) { const char* e = getenv("CHASE_HIP_HEEVD_GPU_MIN"); thr = e ? atoi(e) : 384; }
+        if (thr > 0 && n >= thr) return chase_hip_heevd_gpu(c, cplx, n, A, lda, w_host);
+    }
     const int e = ept_of(cplx);
     const size_t colb = (size_t)n * sizeof(double) * e;
     RCCHK(c->ensure_hstage(colb * n));

@@ -204,6 +204,44 @@ static int g3(chase_hip_ctx* c, bool cplx, char op, int m, int n, int k, double 
     return 0;
 }
 
+namespace chase_hip {
+// Cm (m x ncols, ldc) <- Q * Cm with Q = H_0 H_1 ... H_{nref-1}, reflectors in QR storage (unit at (k,k), tail below) in
+// Vstore (m rows, ldv), scalars tau on the device.  Blocked compact-WY, backward over panels (LAPACK xUNMQR 'L','N').
+int hh_apply_q_left(chase_hip_ctx* c, bool cplx, const double* Vstore, long ldv, int m, int nref, const double* tau,
+                    double* Cm, long ldc, int ncols)
+{
+    if (m <= 0 || nref <= 0 || ncols <= 0) return 0;
+    const int E = cplx ? 2 : 1;
+    hipStream_t st = c->stream;
+    const int npan = (nref + HNB - 1) / HNB;
+    const size_t szV = (size_t)m * HNB * E, szW = (size_t)HNB * ncols * E, szG = (size_t)HNB * HNB * E;
+    double* blk = nullptr;
+    if (hipMalloc((void**)&blk, (szV + 2 * szW + 2 * szG) * sizeof(double)) != hipSuccess)
+        return set_error(CHASE_HIP_ENOMEM, "apply_q: scratch allocation failed");
+    double* Vb = blk; double* W1 = Vb + szV; double* W2 = W1 + szW; double* G = W2 + szW; double* T = G + szG;
+    auto body = [&]() -> int {
+        for (int p = npan - 1; p >= 0; --p) {
+            const int j0 = p * HNB, nb = (nref - j0 < HNB) ? nref - j0 : HNB;
+            const int rows = m - j0;
+            unsigned gx = (unsigned)((rows + 1023) / 1024); if (gx > 64) gx = 64; if (gx < 1) gx = 1;
+            KL(hipLaunchKernelGGL(extract_v_kernel, dim3(gx, nb), dim3(256), 0, st, Vstore, ldv, m, j0, nb, E, Vb));
+            RC(g3(c, cplx, 'C', nb, nb, rows, 1.0, Vb, rows, Vb, rows, 0.0, G, nb));
+            if (cplx) KL(hipLaunchKernelGGL(larft_kernel<true>, dim3(1), dim3(64), 0, st, G, nb, tau + (size_t)j0 * E, T));
+            else      KL(hipLaunchKernelGGL(larft_kernel<false>, dim3(1), dim3(64), 0, st, G, nb, tau + (size_t)j0 * E, T));
+            double* Cs = Cm + (size_t)j0 * E;
+            RC(g3(c, cplx, 'C', nb, ncols, rows, 1.0, Vb, rows, Cs, ldc, 0.0, W1, nb));
+            RC(g3(c, cplx, 'N', nb, ncols, nb, 1.0, T, HNB, W1, nb, 0.0, W2, nb));
+            RC(g3(c, cplx, 'N', rows, ncols, nb, -1.0, Vb, rows, W2, nb, 1.0, Cs, ldc));
+        }
+        return 0;
+    };
+    const int rc = body();
+    hipStreamSynchronize(st);
+    hipFree(blk);
+    return rc;
+}
+} // namespace chase_hip
+
 extern "C" int chase_hip_houseqr(chase_hip_ctx* c, int cplx_, int m, int n, void* V_, long ldv)
 {
     if (!c || !V_) return set_error(CHASE_HIP_EINVAL, "houseqr: NULL argument");

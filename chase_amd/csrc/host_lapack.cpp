@@ -22,12 +22,15 @@ typedef void (*zheevd_t)(const char*, const char*, const int*, void*, const int*
 typedef void (*dstemr_t)(const char*, const char*, const int*, double*, double*, const double*, const double*,
                          const int*, const int*, int*, double*, double*, const int*, const int*, int*, int*, double*,
                          const int*, int*, const int*, int*);
+typedef void (*dstedc_t)(const char*, const int*, double*, double*, double*, const int*, double*, const int*, int*,
+                         const int*, int*);
 typedef void (*set_threads_t)(int);
 
 static void* g_handle = nullptr;
 static dsyevd_t g_dsyevd = nullptr;
 static zheevd_t g_zheevd = nullptr;
 static dstemr_t g_dstemr = nullptr;
+static dstedc_t g_dstedc = nullptr;
 static set_threads_t g_set_threads = nullptr;
 static std::string g_provider;
 static std::mutex g_mu;
@@ -53,6 +56,7 @@ static bool try_lib(const char* path)
     dstemr_t c = (dstemr_t)sym_any(h, "dstemr");
     if (!a || !b || !c) { dlclose(h); return false; }
     g_handle = h; g_dsyevd = a; g_zheevd = b; g_dstemr = c;
+    g_dstedc = (dstedc_t)sym_any(h, "dstedc");
     g_set_threads = (set_threads_t)dlsym(h, "scipy_openblas_set_num_threads");
     if (!g_set_threads) g_set_threads = (set_threads_t)dlsym(h, "openblas_set_num_threads");
     if (!g_set_threads) g_set_threads = (set_threads_t)dlsym(h, "MKL_Set_Num_Threads");
@@ -141,6 +145,31 @@ int host_heevd(bool cplx, int n, double* A, int lda, double* w)
         snprintf(buf, sizeof buf, "host heevd failed, info = %d", info);
         return set_error(info > 0 ? CHASE_HIP_ENOTCONV : CHASE_HIP_EINVAL, buf);
     }
+    return 0;
+}
+
+// divide & conquer tridiagonal eigensolver (compz = 'I'): eigenvalues ascending in d (copied to w), eigenvectors in Z
+int host_stedc(int n, double* d, double* e, double* w, double* Z, int ldz)
+{
+    if (n <= 0) return 0;
+    int rc = lapack_bind(nullptr);
+    if (rc) return rc;
+    if (!g_dstedc) return host_stemr(n, d, e, w, Z, ldz);
+    const char compz = 'I';
+    int info = 0, lwork = -1, liwork = -1, iwq;
+    double wq;
+    g_dstedc(&compz, &n, d, e, Z, &ldz, &wq, &lwork, &iwq, &liwork, &info);
+    if (info) return set_error(CHASE_HIP_ENOTCONV, "dstedc workspace query failed");
+    lwork = (int)wq; liwork = iwq;
+    std::vector<double> work((size_t)lwork);
+    std::vector<int> iwork((size_t)liwork);
+    g_dstedc(&compz, &n, d, e, Z, &ldz, work.data(), &lwork, iwork.data(), &liwork, &info);
+    if (info != 0) {
+        char buf[128];
+        snprintf(buf, sizeof buf, "host stedc failed, info = %d", info);
+        return set_error(CHASE_HIP_ENOTCONV, buf);
+    }
+    for (int i = 0; i < n; ++i) w[i] = d[i];
     return 0;
 }
 

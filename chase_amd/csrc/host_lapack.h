@@ -12,5 +12,6 @@ const char* lapack_provider();
 int host_heevd(bool cplx, int n, double* A, int lda, double* w);
 // symmetric tridiagonal: all eigenpairs.  d[n], e[n] (e[n-1] workspace) are destroyed.  Z is n x n column-major.
 int host_stemr(int n, double* d, double* e, double* w, double* Z, int ldz);
+int host_stedc(int n, double* d, double* e, double* w, double* Z, int ldz);   // divide & conquer, same contract
 void lapack_set_threads(int nthreads);
 }

@@ -20,7 +20,7 @@ def run_distributed(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     dist.init_process_group("gloo")
-    workload = args.workload or B.DEFAULT_WORKLOAD
+    workload = args.workload or B.DEFAULT_BY_GPUS.get(world, B.DEFAULT_WORKLOAD)
     N, cplx, nev, nex = B.WORKLOADS[workload]
     if args.n:
         N = args.n
@@ -30,7 +30,7 @@ def run_distributed(args):
     ctx = Context(local_rank % max(ndev, 1))
     pg = cd.make_process_groups(nprow, npcol)
     grid = cd.Grid(ctx, nprow, npcol, rank, transport=os.environ.get("CHASE_HIP_TRANSPORT", "rccl"), pg=pg)
-    mb = nb = args.block_cyclic
+    mb = nb = args.block_cyclic if args.block_cyclic >= 0 else B.DEFAULT_BLOCK_CYCLIC.get(workload, 0)
     rl, cl = cd.Layout(N, mb, nprow), cd.Layout(N, nb, npcol)
     dH = cd.gen_clement_local(ctx, N, cplx, rl, cl, myrow, mycol, scale=B.MATRIX_SCALE / N, perturb=B.MATRIX_PERTURB)
     ctx.sync()
@@ -68,7 +68,7 @@ def run_distributed(args):
         out = {
             "metric": "chebyshev_filter_hemm_gflops", "value": gflops, "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.workload else "weak", "vs_baseline": None,
             "dtype": "complex f64" if cplx else "f64", "data": "synthetic",
             "config": {"workload": f"{workload}: ChASE solve, perturbed Clement-type Hermitian (x100/N) N={N} "
                                    f"{'complex' if cplx else 'real'} fp64, nev={nev} nex={nex}, tol 1e-10, deg 20 opt, "

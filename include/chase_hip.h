@@ -138,6 +138,9 @@ int chase_hip_houseqr(chase_hip_ctx* ctx, int cplx, int m, int n, void* V, long 
 
 /* ---- Rayleigh-Ritz: host HEEVD of a device matrix ('V','L'), eigenvectors back on the device -------------------- */
 int chase_hip_heevd(chase_hip_ctx* ctx, int cplx, int n, void* A, long lda, double* w_host);
+/* same contract; Householder tridiagonalisation + back-transformation on the GPU, tridiagonal stemr on the host
+ * (chase_hip_heevd switches to it for n >= 384; env CHASE_HIP_HEEVD_GPU_MIN) */
+int chase_hip_heevd_gpu(chase_hip_ctx* ctx, int cplx, int n, void* A, long lda, double* w_host);
 int chase_hip_heevd_host(int cplx, int n, void* A_host, long lda, double* w_host); /* host-only twin (provider check) */
 /* host-only: all eigenpairs of a symmetric tridiagonal (Lanczos; lapackpp::t_stemr, cpu/lanczos.hpp:188) */
 int chase_hip_stemr_host(int n, double* d, double* e, double* w, double* Z, int ldz);

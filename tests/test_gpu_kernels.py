@@ -218,11 +218,11 @@ def test_shift_swap_lacpy_resid(ctx, cplx):
 
 
 @pytest.mark.parametrize("cplx", [False, True])
-def test_heevd_matches_scipy(ctx, cplx):
+@pytest.mark.parametrize("n", [150, 385, 700])          # < 384: host LAPACK; >= 384: GPU tridiagonalisation path
+def test_heevd_matches_scipy(ctx, cplx, n):
     from chase_amd.capi import lib, check
     import scipy.linalg as sla
     rng = np.random.default_rng(3)
-    n = 150
     X = rnd(rng, (n, n), cplx)
     A = np.asfortranarray(X + X.conj().T)
     dA = ctx.array(A)
@@ -232,3 +232,25 @@ def test_heevd_matches_scipy(ctx, cplx):
     assert np.max(np.abs(w - sla.eigvalsh(A))) <= 100 * EPS * np.abs(w).max()
     assert np.linalg.norm(A @ Z - Z * w[None, :]) <= 1e-12 * np.linalg.norm(A)
     assert O.orthogonality(Z) <= 50 * EPS
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n", [3, 4, 65, 257])
+def test_heevd_gpu_small_and_degenerate(ctx, cplx, n):
+    """GPU tridiagonalisation on tiny sizes and on a matrix with repeated eigenvalues / zero sub-columns."""
+    from chase_amd.capi import lib
+    import scipy.linalg as sla
+    rng = np.random.default_rng(n)
+    X = rnd(rng, (n, n), cplx)
+    Q, _ = np.linalg.qr(X)
+    lam = np.repeat(np.arange(1.0, n // 2 + 2), 2)[:n]            # every eigenvalue twice
+    A = np.asfortranarray((Q * lam[None, :]) @ Q.conj().T)
+    A[:, 0] = 0; A[0, :] = 0; A[0, 0] = 7.5                        # decoupled first row/column: tau = 0 branch
+    A = np.asfortranarray((A + A.conj().T) / 2)
+    dA = ctx.array(A)
+    w = np.zeros(n)
+    assert lib.chase_hip_heevd_gpu(ctx.h, int(cplx), n, dA.ptr, n, w.ctypes.data) == 0, lib.chase_hip_last_error()
+    Z = dA.download()
+    assert np.max(np.abs(w - sla.eigvalsh(A))) <= 200 * EPS * np.abs(w).max()
+    assert np.linalg.norm(A @ Z - Z * w[None, :]) <= 1e-12 * max(1.0, np.linalg.norm(A))
+    assert O.orthogonality(Z) <= 100 * EPS
