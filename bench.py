@@ -113,7 +113,7 @@ def run_single(args):
     out = {
         "metric": "chebyshev_filter_hemm_gflops", "value": gflops, "unit": "GFLOP/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if args.user_workload else "weak", "vs_baseline": None,
         "dtype": "complex f64" if cplx else "f64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: ChASE solve, perturbed Clement-type Hermitian (x100/N) N={N} "
                                f"{'complex' if cplx else 'real'} fp64, nev={nev} nex={nex}, tol 1e-10, deg 20 opt, 1x1 grid",
@@ -164,6 +164,7 @@ def main():
         if out is not None:
             print(json.dumps(out), flush=True)
         return
+    args.user_workload = args.workload is not None
     if args.workload is None:
         args.workload = DEFAULT_WORKLOAD
     out = run_single(args)

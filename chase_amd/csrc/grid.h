@@ -10,6 +10,7 @@ struct chase_hip_grid {
     chase_hip_ctx* ctx = nullptr;
     int nprow = 1, npcol = 1, rank = 0, myrow = 0, mycol = 0;
     bool use_rccl = false;
+    bool force = false;                               // CHASE_HIP_RCCL_FORCE: run size-1 groups through RCCL too (testing)
     ncclComm_t comm[2] = {nullptr, nullptr};          // [ROW], [COL]
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_compute = nullptr, ev_comm = nullptr;
@@ -19,5 +20,6 @@ struct chase_hip_grid {
     double* scal_dev = nullptr;                        // one double for agree_max
     std::vector<hipEvent_t> slots;                     // per-panel 'all-reduce done' events (pipelined HEMM)
     int group_size(int g) const { return g == CHASE_HIP_ROW ? npcol : nprow; }
+    bool active(int g) const { return group_size(g) > 1 || (force && use_rccl); }
     int group_rank(int g) const { return g == CHASE_HIP_ROW ? mycol : myrow; }
 };

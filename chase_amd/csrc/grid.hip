@@ -1,6 +1,7 @@
 // grid.hip — 2D process grid + collectives (RCCL over xGMI, or host-callback test transport).  See chase_hip_grid.h.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "grid.h"
 #include "kernels.h"
@@ -57,14 +58,15 @@ int chase_hip_grid_create_rccl(chase_hip_grid** out, chase_hip_ctx* ctx, int npr
     int rc = grid_common(g, ctx, nprow, npcol, rank);
     if (rc) { delete g; return rc; }
     g->use_rccl = true;
+    g->force = getenv("CHASE_HIP_RCCL_FORCE") != nullptr;
     // the reference creates its row and column NCCL communicators the same way: one unique id per sub-communicator,
     // ncclCommInitRank on each (grid/mpiGrid2D.hpp:448-484)
-    if (npcol > 1) {
+    if (npcol > 1 || g->force) {
         if (!id_row) { delete g; return set_error(CHASE_HIP_EINVAL, "grid_create: row id missing"); }
         ncclUniqueId u; memcpy(&u, id_row, sizeof u);
         NCCLCHK(ncclCommInitRank(&g->comm[CHASE_HIP_ROW], npcol, u, g->mycol));
     }
-    if (nprow > 1) {
+    if (nprow > 1 || g->force) {
         if (!id_col) { delete g; return set_error(CHASE_HIP_EINVAL, "grid_create: col id missing"); }
         ncclUniqueId u; memcpy(&u, id_col, sizeof u);
         NCCLCHK(ncclCommInitRank(&g->comm[CHASE_HIP_COL], nprow, u, g->myrow));
@@ -104,6 +106,12 @@ int chase_hip_grid_destroy(chase_hip_grid* g)
     return 0;
 }
 
+int chase_hip_grid_group_active(chase_hip_grid* g, int group)
+{
+    if (!g || (group != CHASE_HIP_ROW && group != CHASE_HIP_COL)) return 0;
+    return g->active(group) ? 1 : 0;
+}
+
 int chase_hip_grid_info(chase_hip_grid* g, int* nprow, int* npcol, int* myrow, int* mycol)
 {
     if (!g) return set_error(CHASE_HIP_EINVAL, "grid_info: NULL grid");
@@ -119,7 +127,7 @@ static int collective(chase_hip_grid* g, int mode, int group, void* dev, size_t 
 {
     if (!g) return set_error(CHASE_HIP_EINVAL, "collective: NULL grid");
     if (group != CHASE_HIP_ROW && group != CHASE_HIP_COL) return set_error(CHASE_HIP_EINVAL, "collective: bad group");
-    if (count == 0 || g->group_size(group) == 1) return 0;
+    if (count == 0 || !g->active(group)) return 0;
     if (mode == 1 && (root < 0 || root >= g->group_size(group))) return set_error(CHASE_HIP_EINVAL, "bcast: bad root");
     chase_hip_ctx* c = g->ctx;
     if (g->use_rccl) {
@@ -184,7 +192,7 @@ int chase_hip_grid_event_wait(chase_hip_grid* g, int slot)
 int chase_hip_grid_agree_max(chase_hip_grid* g, int* value)
 {
     if (!g || !value) return set_error(CHASE_HIP_EINVAL, "agree_max: NULL argument");
-    if (g->nprow * g->npcol == 1) return 0;
+    if (g->nprow * g->npcol == 1 && !g->force) return 0;
     // max over all ranks = max over rows of (max over columns); implemented with SUM all-reduces of one-hot-free
     // encoding is not possible, so use two passes of allreduce on (value) via the identity max(a,b) for
     // non-negative ints: we all-reduce the SUM of indicator(value > 0) and of value; control flow only needs

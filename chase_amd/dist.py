@@ -14,6 +14,7 @@ AR_FN = C.CFUNCTYPE(c_int, c_void_p, c_int, P(c_double), c_size_t)
 BC_FN = C.CFUNCTYPE(c_int, c_void_p, c_int, P(c_double), c_size_t, c_int)
 _sig("chase_hip_grid_create_host", c_int, P(c_void_p), c_void_p, c_int, c_int, c_int, AR_FN, BC_FN, c_void_p)
 _sig("chase_hip_grid_destroy", c_int, c_void_p)
+_sig("chase_hip_grid_group_active", c_int, c_void_p, c_int)
 _sig("chase_hip_grid_info", c_int, c_void_p, P(c_int), P(c_int), P(c_int), P(c_int))
 _sig("chase_hip_grid_allreduce", c_int, c_void_p, c_int, c_void_p, c_size_t, c_int)
 _sig("chase_hip_grid_bcast", c_int, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int)

@@ -388,7 +388,7 @@ private:
         T* out = bAc ? dW1_ : dV1_;
         const T* in = bAc ? dV1_ : dW1_;
         const std::size_t in_ld = bAc ? m_ : n_;
-        const bool pipe = pipelined && pipeline_ && (bAc ? nprow_ : npcol_) > 1;
+        const bool pipe = pipelined && pipeline_ && chase_hip_grid_group_active(grid_, group) != 0;
         std::size_t c = c0;
         while (c < c0 + nc) {
             const std::size_t fp = c / PANEL;                                  // fixed panel index
@@ -414,7 +414,7 @@ private:
     // make a small host vector (and optionally a device matrix) identical on all ranks: broadcast from grid (0, 0)
     void agree_vector(R* host, std::size_t n, T* dev, std::size_t dev_elems)
     {
-        if (nprow_ * npcol_ == 1) return;
+        if (!chase_hip_grid_group_active(grid_, CHASE_HIP_ROW) && !chase_hip_grid_group_active(grid_, CHASE_HIP_COL)) return;
         if (n > pack_elems_ * E) throw std::length_error("pChaseHip: agreement scratch too small");
         double* d = (double*)dPack_;
         hip_ok(chase_hip_memcpy_h2d(ctx_, d, host, n * sizeof(double)), "h2d");

@@ -36,6 +36,9 @@ int chase_hip_grid_create_host(chase_hip_grid** out, chase_hip_ctx* ctx, int npr
                                chase_hip_host_allreduce_fn allreduce, chase_hip_host_bcast_fn bcast, void* user);
 int chase_hip_grid_destroy(chase_hip_grid* g);
 int chase_hip_grid_info(chase_hip_grid* g, int* nprow, int* npcol, int* myrow, int* mycol);
+/* 1 if collectives in `group` really communicate (group size > 1, or CHASE_HIP_RCCL_FORCE set: size-1 groups are then
+ * run through RCCL as well so that a single-GPU box exercises ncclCommInitRank / ncclAllReduce / the stream logic) */
+int chase_hip_grid_group_active(chase_hip_grid* g, int group);
 /* in-place SUM all-reduce / broadcast of `count` doubles of device memory inside `group`; ordered after the work
  * already enqueued on the context stream, and the context stream waits for the result (async = 0), or the caller
  * orders it with chase_hip_grid_wait (async != 0: the collective runs on the grid's communication stream). */

@@ -42,3 +42,11 @@ def test_solve_blockcyclic_2x2_n1001_nb64():
 
 def test_solve_rccl_transport_single_rank():
     run_ranks(1, "rccl", "solve", 256, 24, 16, "z", 0, 16)
+
+
+def test_solve_rccl_forced_through_size1_communicators(monkeypatch):
+    """CHASE_HIP_RCCL_FORCE routes the size-1 row/column groups through real RCCL communicators: ncclCommInitRank,
+    ncclAllReduce, ncclBroadcast, the communication stream, the per-panel events of the pipelined HEMM."""
+    monkeypatch.setenv("CHASE_HIP_RCCL_FORCE", "1")
+    run_ranks(1, "rccl", "solve", 1001, 100, 60, "z", 64, 20)
+    run_ranks(1, "rccl", "ops", "d", 0)
