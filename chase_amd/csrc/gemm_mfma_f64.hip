@@ -58,7 +58,19 @@ struct Cfg {
     static constexpr int B_PASSES = B_UNITS / NTHREADS;
     static constexpr int STAGE_UNITS = A_UNITS + B_UNITS;
     static constexpr int EPT = CPLX ? 2 : 1;        // doubles per element
+    // complex: 3 LDS stages filled by global_load_lds two K steps ahead (72 KB per workgroup, two workgroups per CU);
+    // real: 2 stages through registers (3 x 32 KB x 2 workgroups would not fit the 160 KB LDS)
+    static constexpr int STAGES = CPLX ? 3 : 2;
+    static constexpr int A_GLDS = A_UNITS / 64, B_GLDS = B_UNITS / 64;     // wave instructions per tile
+    static constexpr int GLDS_PER_WAVE = (A_GLDS + B_GLDS) / 4;
 };
+
+// LDS image of a K-contiguous operand tile (rows x 8 sixteen-byte units): unit ku of row r sits at r*8 + (ku ^ f(r)),
+// f(r) = (r >> 1) & 7.  One wave instruction of 64 x 16 B covers 8 whole rows, so the image can be filled either by
+// ds_write_b128 (8-lane groups write one contiguous 128-B row) or directly by global_load_lds (lane l <- row l/8, unit
+// (l%8) ^ f(row): the swizzle lives on the SOURCE address); the 16-lane groups of the fragment ds_read_b128 hit 16
+// distinct 16-byte slots (conflict-free, SQ_LDS_BANK_CONFLICT = 0 measured).
+__device__ __forceinline__ int kidx(int r, int ku) { return r * 8 + (ku ^ ((r >> 1) & 7)); }
 
 // bijective XCD remap (blocks b and b+8 share an XCD): gives each XCD a contiguous range of logical tiles
 __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
@@ -78,6 +90,7 @@ struct GemmArgs {
     // of tail_kchunk each, written as raw BM x BN partial slabs and combined by tail_reduce_kernel in a fixed order.
     int full_tiles, tail_sk, tail_kchunk;
     double* slabs;
+    int glds_ok;                                     // operands are 16-byte addressable: direct global -> LDS copies allowed
     double alpha_re, alpha_im, beta_re, beta_im;
 };
 
@@ -91,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
     constexpr int EPT = C_::EPT, KPU = C_::KPU, RPU = C_::RPU;
     constexpr int UM = BM / RPU;                    // units per k-column of an M-contiguous A tile
 
-    extern __shared__ __attribute__((aligned(16))) d2_t lds[];   // [2][STAGE_UNITS]
+    extern __shared__ __attribute__((aligned(16))) d2_t lds[];   // [STAGES][STAGE_UNITS]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -196,14 +209,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                 sA[idx] = ra[ps];                                   // [k][unit], identical to the load order
             } else {
                 const int r = idx >> 3, ku = idx & 7;
-                sA[ku * BM + (r ^ ku)] = ra[ps];
+                sA[kidx(r, ku)] = ra[ps];
             }
         }
         #pragma unroll
         for (int ps = 0; ps < C_::B_PASSES; ++ps) {
             const int idx = ps * 256 + tid;
             const int r = idx >> 3, ku = idx & 7;
-            sB[ku * BN + (r ^ ku)] = rb[ps];
+            sB[kidx(r, ku)] = rb[ps];
         }
     };
 
@@ -222,23 +235,65 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
     auto compute = [&](int stage) {
         const d2_t* sA = lds + stage * C_::STAGE_UNITS;
         const d2_t* sB = sA + C_::A_UNITS;
-        #pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {            // two 4-unit chunks along K per stage
-            const int ku = 4 * ch + q;
-            d2_t fb[TN];
+        if constexpr (CPLX) {
+            // fragments of BOTH 4-deep chunks are fetched up front so that the second chunk's LDS latency is covered by
+            // the first chunk's 32 MFMAs (the compiler otherwise issues those reads only after the last MFMA)
+            d2_t fb[2][TN], fa[2][TM];
             #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int r = wcol + 16 * j + c16;
-                fb[j] = sB[ku * BN + (r ^ ku)];
+            for (int ch = 0; ch < 2; ++ch) {
+                const int ku = 4 * ch + q;
+                #pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int r = wcol + 16 * j + c16;
+                    fb[ch][j] = sB[kidx(r, ku)];
+                }
+                #pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int r = wrow + 16 * i + c16;
+                    if constexpr (OPA_C) fa[ch][i] = sA[kidx(r, ku)];
+                    else                 fa[ch][i] = sA[ku * UM + r];
+                }
             }
-            if constexpr (!CPLX) {
+            __builtin_amdgcn_sched_barrier(0);
+            #pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                // op=N: (ar + i ai)(br + i bi): re = br ar - bi ai, im = bi ar + br ai
+                // op=C: (ar - i ai)(br + i bi): re = br ar + bi ai, im = bi ar - br ai      -> one negated B value per tile
+                double nb[TN];
+                #pragma unroll
+                for (int j = 0; j < TN; ++j) nb[j] = OPA_C ? -fb[ch][j].x : -fb[ch][j].y;
+                #pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    #pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ch][j].x, fa[ch][i].x, acc[0][j][i], 0, 0, 0);
+                        acc[1][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ch][j].y, fa[ch][i].x, acc[1][j][i], 0, 0, 0);
+                    }
+                #pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    #pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(OPA_C ? fb[ch][j].y : nb[j], fa[ch][i].y, acc[0][j][i], 0, 0, 0);
+                        acc[1][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(OPA_C ? nb[j] : fb[ch][j].x, fa[ch][i].y, acc[1][j][i], 0, 0, 0);
+                    }
+            }
+        } else {
+            #pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {            // two 4-unit chunks along K per stage
+                const int ku = 4 * ch + q;
+                d2_t fb[TN];
+                #pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int r = wcol + 16 * j + c16;
+                    fb[j] = sB[kidx(r, ku)];
+                }
                 // real: per chunk two MFMA k-steps s = 0,1 using k = 8*ch + 2*q + s
                 double fa[TM][2];                   // [tile][s]
                 if constexpr (OPA_C) {
                     #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         const int r = wrow + 16 * i + c16;
-                        const d2_t v = sA[ku * BM + (r ^ ku)];
+                        const d2_t v = sA[kidx(r, ku)];
                         fa[i][0] = v.x; fa[i][1] = v.y;
                     }
                 } else {
@@ -260,41 +315,72 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                         for (int i = 0; i < TM; ++i)
                             acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(
                                 s == 0 ? fb[j].x : fb[j].y, fa[i][s], acc[0][j][i], 0, 0, 0);
-            } else {
-                d2_t fa[TM];
-                #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int r = wrow + 16 * i + c16;
-                    if constexpr (OPA_C) fa[i] = sA[ku * BM + (r ^ ku)];
-                    else                 fa[i] = sA[ku * UM + r];
-                }
-                // op=N: (ar + i ai)(br + i bi);  op=C: (ar - i ai)(br + i bi)
-                double ai_re[TM], ai_im[TM];
-                #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    ai_re[i] = OPA_C ? fa[i].y : -fa[i].y;         // multiplies bi into the real part
-                    ai_im[i] = OPA_C ? -fa[i].y : fa[i].y;         // multiplies br into the imaginary part
-                }
-                #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    #pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].x, fa[i].x, acc[0][j][i], 0, 0, 0);
-                        acc[1][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].y, fa[i].x, acc[1][j][i], 0, 0, 0);
-                    }
-                #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    #pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].y, ai_re[i], acc[0][j][i], 0, 0, 0);
-                        acc[1][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j].x, ai_im[i], acc[1][j][i], 0, 0, 0);
-                    }
             }
         }
     };
 
     // ---- main loop ----------------------------------------------------------------------------------------------
-    if (nkt > 0) {
+    bool done = false;
+    {
+        // Interior workgroups: asynchronous global -> LDS copies (global_load_lds_dwordx4, no staging registers, no
+        // ds_write pass); complex: three LDS stages, tile kt+2 in flight while tile kt is multiplied; real: two stages,
+        // tile kt+1 in flight.  One raw s_barrier and one COUNTED vmcnt per K step.
+        constexpr int DEPTH = C_::STAGES - 1;
+        const int nfull = (kend - kbeg) / BK;
+        if (interior && nfull >= 1 && p.glds_ok) {
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+            auto issue = [&](int k0, int stage) {
+                d2_t* sA = lds + stage * C_::STAGE_UNITS;
+                d2_t* sB = sA + C_::A_UNITS;
+                #pragma unroll
+                for (int u = 0; u < C_::A_GLDS / 4; ++u) {
+                    const int t = wv * (C_::A_GLDS / 4) + u;
+                    const double* g;
+                    if constexpr (!OPA_C) {
+                        // [k][unit] image: complex 128 units per k row (two instructions), real 64 units (one)
+                        const int kk = CPLX ? (t >> 1) : t, half = CPLX ? (t & 1) : 0;
+                        g = p.A + ((long)(k0 + kk) * p.lda + row0) * EPT + (long)(half * 64 + lane) * 2;
+                    } else {
+                        const int r = 8 * t + (lane >> 3), ku = (lane & 7) ^ ((r >> 1) & 7);
+                        g = p.A + ((long)(row0 + r) * p.lda + k0 + ku * KPU) * EPT;
+                    }
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(sA + t * 64), 16, 0, 0);
+                }
+                #pragma unroll
+                for (int u = 0; u < C_::B_GLDS / 4; ++u) {
+                    const int t = wv * (C_::B_GLDS / 4) + u;
+                    const int r = 8 * t + (lane >> 3), ku = (lane & 7) ^ ((r >> 1) & 7);
+                    const double* g = p.B + ((long)(col0 + r) * p.ldb + k0 + ku * KPU) * EPT;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(sB + t * 64), 16, 0, 0);
+                }
+            };
+            issue(kbeg, 0);
+            if (DEPTH > 1 && nfull > 1) issue(kbeg + BK, 1);
+            for (int kt = 0; kt < nfull; ++kt) {
+                // my own copies of tile kt have landed (with three stages tile kt+1 may stay in flight) ...
+                if (DEPTH > 1 && kt + 1 < nfull) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C_::GLDS_PER_WAVE) : "memory");
+                else                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // ... and after the barrier everybody's have; everybody has also finished reading the stage refilled next
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (kt + DEPTH < nfull) issue(kbeg + (kt + DEPTH) * BK, (kt + DEPTH) % C_::STAGES);
+                compute(kt % C_::STAGES);
+            }
+            // a partial last K tile goes through the guarded register path into the stage nobody reads any more
+            if (nfull * BK < kend - kbeg) {
+                const int st = nfull % C_::STAGES;
+                __syncthreads();
+                load_tile(kbeg + nfull * BK);
+                store_tile(st);
+                __syncthreads();
+                compute(st);
+            }
+            done = true;
+        }
+    }
+    if (!done && nkt > 0) {
         load_tile(kbeg);
         store_tile(0);
         __syncthreads();
@@ -440,8 +526,10 @@ static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha,
     if (sk <= 1) { full = tiles; tail = 0; sk = 1; }         // nothing to split: every tile is a whole tile
     int kchunk = ((nkt + sk - 1) / sk) * C_::BK;
     a.full_tiles = (int)full; a.tail_sk = sk; a.tail_kchunk = kchunk; a.slabs = ws;
+    // global_load_lds moves 16 bytes per lane: complex elements always qualify, real ones need even leading dimensions
+    a.glds_ok = (((uintptr_t)A | (uintptr_t)B) % 16 == 0) && (CPLX || ((lda % 2 == 0) && (ldb % 2 == 0)));
     const unsigned grid = (unsigned)(full + tail * sk);
-    const size_t lds_bytes = 2 * C_::STAGE_UNITS * sizeof(d2_t);
+    const size_t lds_bytes = (size_t)C_::STAGES * C_::STAGE_UNITS * sizeof(d2_t);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
