@@ -327,7 +327,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
         // tile kt+1 in flight.  One raw s_barrier and one COUNTED vmcnt per K step.
         constexpr int DEPTH = C_::STAGES - 1;
         const int nfull = (kend - kbeg) / BK;
-        if (interior && nfull >= 1 && p.glds_ok) {
+        // column-edge workgroups qualify too: B rows past n are clamped to the last valid column (their products are
+        // never stored), only a ragged M edge needs the guarded register path
+        if ((row0 + BM <= p.m) && nfull >= 1 && p.glds_ok) {
             const int wv = __builtin_amdgcn_readfirstlane(wave);
             auto issue = [&](int k0, int stage) {
                 d2_t* sA = lds + stage * C_::STAGE_UNITS;
@@ -351,7 +353,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                 for (int u = 0; u < C_::B_GLDS / 4; ++u) {
                     const int t = wv * (C_::B_GLDS / 4) + u;
                     const int r = 8 * t + (lane >> 3), ku = (lane & 7) ^ ((r >> 1) & 7);
-                    const double* g = p.B + ((long)(col0 + r) * p.ldb + k0 + ku * KPU) * EPT;
+                    const int gc = min(col0 + r, p.n - 1);
+                    const double* g = p.B + ((long)gc * p.ldb + k0 + ku * KPU) * EPT;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                      (__attribute__((address_space(3))) void*)(sB + t * 64), 16, 0, 0);
                 }
