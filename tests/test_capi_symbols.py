@@ -14,7 +14,8 @@ def _declared(header):
 
 def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(ROOT, "chase_amd", "lib", "libchase_hip.so"))
-    names = _declared("chase_hip.h") + _declared("chase_hip_solver.h")
+    names = _declared("chase_hip.h") + _declared("chase_hip_solver.h") + _declared("chase_hip_grid.h")
+    names += ["dchase_init_", "dchase_", "dchase_finalize_", "zchase_init_", "zchase_", "zchase_finalize_"]
     assert len(names) > 50
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing

@@ -159,3 +159,36 @@ def test_check_symmetry(ctx):
     s2 = Solver(ctx, H2, 8, 8)
     assert not s2.checkSymmetryEasy()
     s.close(); s2.close()
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_c_interface_shim(ctx, cplx):
+    """dchase_init_/dchase_/dchase_finalize_ (interface/chase_c_interface.h:13-41), incl. the approximate-restart mode of
+    the sequence examples (docs/example/sequence.rst): a second solve started from the previous eigenvectors."""
+    import ctypes as C
+    from chase_amd.capi import lib
+    N, nev, nex = 256, 24, 16
+    H = O.clement(N, cplx)
+    V = np.zeros((N, nev + nex), dtype=H.dtype, order="F")
+    lam = np.zeros(nev + nex)
+    pre = "z" if cplx else "d"
+    ci = lambda v: C.byref(C.c_int(v))
+    init = C.c_int(0)
+    getattr(lib, pre + "chase_init_")(ci(N), ci(nev), ci(nex), C.c_void_p(H.ctypes.data), ci(N), C.c_void_p(V.ctypes.data),
+                                      C.c_void_p(lam.ctypes.data), C.byref(init))
+    assert init.value == 1
+    solve = getattr(lib, pre + "chase_")
+    solve(ci(16), C.byref(C.c_double(1e-10)), C.c_char_p(b"R"), C.c_char_p(b"S"), C.c_char_p(b"C"))
+    assert np.max(O.residuals(H, lam[:nev].copy(), V[:, :nev])) < RESID_TOL
+    lam1 = lam[:nev].copy()
+    # slightly perturbed problem, approximate mode: V and ritzv from the previous solve are the start
+    H2 = np.asfortranarray(H + 1e-4 * np.diag(np.arange(N) / N))
+    getattr(lib, pre + "chase_init_")(ci(N), ci(nev), ci(nex), C.c_void_p(H2.ctypes.data), ci(N), C.c_void_p(V.ctypes.data),
+                                      C.c_void_p(lam.ctypes.data), C.byref(init))
+    assert init.value == 1
+    solve(ci(16), C.byref(C.c_double(1e-10)), C.c_char_p(b"A"), C.c_char_p(b"S"), C.c_char_p(b"C"))
+    assert np.max(O.residuals(H2, lam[:nev].copy(), V[:, :nev])) < RESID_TOL
+    assert np.max(np.abs(lam[:nev] - lam1)) < 1e-3
+    flag = C.c_int(0)
+    getattr(lib, pre + "chase_finalize_")(C.byref(flag))
+    assert flag.value == 1
