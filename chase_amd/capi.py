@@ -364,3 +364,50 @@ class Solver:
         f = c_int()
         check(lib.chase_hip_op_check_symmetry(self.h, C.byref(f)), "checkSymmetryEasy")
         return bool(f.value)
+
+
+_sig("chase_hip_solver_create_pseudo", c_int, P(c_void_p), c_void_p, c_int, c_size_t, c_size_t, c_size_t, c_void_p,
+     c_size_t, c_void_p, c_size_t, c_void_p, c_int)
+_sig("chase_hip_op_hemm_h2", c_int, c_void_p, c_size_t, P(c_double), P(c_double), P(c_double), c_size_t, c_size_t)
+_sig("chase_hip_op_kconj", c_int, c_void_p, c_size_t)
+_sig("chase_hip_pseudo_rr_small", c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p)
+_sig("chase_hip_set_identity", c_int, c_void_p, c_int, c_int, c_void_p, c_long)
+
+
+class PseudoSolver(Solver):
+    """ChaseHipPseudo<T>: pseudo-Hermitian (BSE) Impl — subspace of 2*(nev+nex) columns, chase::Solve_pseudo."""
+
+    def __init__(self, ctx, H, nev, nex):
+        assert H.flags.f_contiguous and H.shape[0] == H.shape[1]
+        self.ctx, self.H = ctx, H
+        self.cplx = bool(np.iscomplexobj(H))
+        self.N, self.nev, self.nex = H.shape[0], nev, nex
+        dt = np.complex128 if self.cplx else np.float64
+        self.ncol = 2 * (nev + nex)
+        self.V = np.zeros((self.N, self.ncol), dtype=dt, order="F")
+        self.ritzv = np.zeros(self.ncol)
+        h = c_void_p()
+        check(lib.chase_hip_solver_create_pseudo(C.byref(h), ctx.h, int(self.cplx), self.N, nev, nex, H.ctypes.data,
+                                                 self.N, self.V.ctypes.data, self.N, self.ritzv.ctypes.data, 0),
+              "solver_create_pseudo")
+        self.h = h
+
+    def resid(self):
+        p = lib.chase_hip_solver_resid(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.ncol,)).copy()
+
+    def HEMM_H2(self, block, alpha, beta, gamma, offset_left, offset_right=0):
+        check(lib.chase_hip_op_hemm_h2(self.h, block, _z2(alpha), _z2(beta), _z2(gamma), offset_left, offset_right),
+              "HEMM_H2")
+
+    def ApplyKconjugate(self, block):
+        check(lib.chase_hip_op_kconj(self.h, block), "ApplyKconjugate")
+
+    def RR(self, block, offset):
+        check(lib.chase_hip_op_rr(self.h, self.ritzv.ctypes.data + 8 * offset, block), "RR")
+
+    def Resd(self, offset):
+        n = self.nev + self.nex - offset
+        out = np.zeros(n)
+        check(lib.chase_hip_op_resd(self.h, self.ritzv.ctypes.data + 8 * offset, out.ctypes.data, offset), "Resd")
+        return out

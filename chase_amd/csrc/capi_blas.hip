@@ -381,6 +381,36 @@ int chase_hip_heevd(chase_hip_ctx* c, int cplx, int n, void* A, long lda, double
     return 0;
 }
 
+/* Pseudo-Hermitian Rayleigh-Ritz, small dense part on the host (cpu/rayleighRitz.hpp:316-383): device A = Q^H S H Q and
+ * M = Q^H S Q (both n x n, ld n) -> device M = back-transformed Ritz vectors (first n/2 columns normalised), Ritz values
+ * to ritzv_host.  Returns the potrf info (> 0) if A is not positive definite. */
+int chase_hip_pseudo_rr_small(chase_hip_ctx* c, int cplx, int n, void* A_dev, void* M_dev, double* ritzv_host)
+{
+    if (!c || !A_dev || !M_dev || !ritzv_host) return set_error(CHASE_HIP_EINVAL, "pseudo_rr_small: NULL argument");
+    if (n <= 0) return 0;
+    const size_t bytes = (size_t)n * n * sizeof(double) * ept_of(cplx);
+    RCCHK(c->ensure_hstage(2 * bytes));
+    double* hA = (double*)c->hstage;
+    double* hM = (double*)((char*)c->hstage + bytes);
+    HIPCHK(hipMemcpyAsync(hA, A_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(hM, M_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const int rc = host_pseudo_rr(cplx != 0, n, hA, hM, ritzv_host);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(M_dev, hM, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+/* A (n x n device, ld lda) <- identity */
+int chase_hip_set_identity(chase_hip_ctx* c, int cplx, int n, void* A, long lda)
+{
+    if (!c || !A) return set_error(CHASE_HIP_EINVAL, "set_identity: NULL argument");
+    HIPCHK(hipMemset2DAsync(A, (size_t)lda * sizeof(double) * ept_of(cplx), 0, (size_t)n * sizeof(double) * ept_of(cplx), n, c->stream));
+    KCHK(shift_diag(c->stream, (double*)A, lda, n, ept_of(cplx), 1.0), "set_identity");
+    return 0;
+}
+
 /* host-only twin of chase_hip_heevd (exercises the bound LAPACK provider without a GPU) */
 int chase_hip_heevd_host(int cplx, int n, void* A_host, long lda, double* w_host)
 {

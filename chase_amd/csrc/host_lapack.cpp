@@ -3,6 +3,7 @@
 // MKL's single dynamic library.  No provider => CHASE_HIP_ELAPACK (the product never falls back silently).
 #include <dlfcn.h>
 #include <glob.h>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -24,6 +25,9 @@ typedef void (*dstemr_t)(const char*, const char*, const int*, double*, double*,
                          const int*, int*, const int*, int*);
 typedef void (*dstedc_t)(const char*, const int*, double*, double*, double*, const int*, double*, const int*, int*,
                          const int*, int*);
+typedef void (*potrf_t)(const char*, const int*, void*, const int*, int*);
+typedef void (*trsm_t)(const char*, const char*, const char*, const char*, const int*, const int*, const void*, const void*,
+                       const int*, void*, const int*);
 typedef void (*set_threads_t)(int);
 
 static void* g_handle = nullptr;
@@ -31,6 +35,8 @@ static dsyevd_t g_dsyevd = nullptr;
 static zheevd_t g_zheevd = nullptr;
 static dstemr_t g_dstemr = nullptr;
 static dstedc_t g_dstedc = nullptr;
+static potrf_t g_dpotrf = nullptr, g_zpotrf = nullptr;
+static trsm_t g_dtrsm = nullptr, g_ztrsm = nullptr;
 static set_threads_t g_set_threads = nullptr;
 static std::string g_provider;
 static std::mutex g_mu;
@@ -57,6 +63,8 @@ static bool try_lib(const char* path)
     if (!a || !b || !c) { dlclose(h); return false; }
     g_handle = h; g_dsyevd = a; g_zheevd = b; g_dstemr = c;
     g_dstedc = (dstedc_t)sym_any(h, "dstedc");
+    g_dpotrf = (potrf_t)sym_any(h, "dpotrf"); g_zpotrf = (potrf_t)sym_any(h, "zpotrf");
+    g_dtrsm = (trsm_t)sym_any(h, "dtrsm");   g_ztrsm = (trsm_t)sym_any(h, "ztrsm");
     g_set_threads = (set_threads_t)dlsym(h, "scipy_openblas_set_num_threads");
     if (!g_set_threads) g_set_threads = (set_threads_t)dlsym(h, "openblas_set_num_threads");
     if (!g_set_threads) g_set_threads = (set_threads_t)dlsym(h, "MKL_Set_Num_Threads");
@@ -144,6 +152,41 @@ int host_heevd(bool cplx, int n, double* A, int lda, double* w)
         char buf[128];
         snprintf(buf, sizeof buf, "host heevd failed, info = %d", info);
         return set_error(info > 0 ? CHASE_HIP_ENOTCONV : CHASE_HIP_EINVAL, buf);
+    }
+    return 0;
+}
+
+// Small dense core of the pseudo-Hermitian Rayleigh-Ritz (reference: cpu::rayleighRitz_v2,
+// linalg/internal/cpu/rayleighRitz.hpp:316-383):  A = Q^H S H Q (Hermitian positive definite), M = Q^H S Q.
+//   A = L L^H;  M <- -L^-1 M L^-H;  heevd(M) -> (w, Z);  w <- -w;  Z <- L^-H Z;  ritz = 1 / w;  normalise Z[:, :n/2]
+// On return M holds Z and w the Ritz values.  Returns potrf info (> 0) if A is not positive definite.
+int host_pseudo_rr(bool cplx, int n, double* A, double* M, double* w)
+{
+    if (n <= 0) return 0;
+    int rc = lapack_bind(nullptr);
+    if (rc) return rc;
+    potrf_t potrf = cplx ? g_zpotrf : g_dpotrf;
+    trsm_t trsm = cplx ? g_ztrsm : g_dtrsm;
+    if (!potrf || !trsm) return set_error(CHASE_HIP_ELAPACK, "host LAPACK provider lacks potrf/trsm");
+    const int E = cplx ? 2 : 1;
+    int info = 0;
+    potrf("L", &n, A, &n, &info);
+    if (info != 0) return info > 0 ? info : set_error(CHASE_HIP_EINVAL, "host potrf: illegal argument");
+    const double one[2] = {1.0, 0.0};
+    trsm("L", "L", "N", "N", &n, &n, one, A, &n, M, &n);
+    trsm("R", "L", "C", "N", &n, &n, one, A, &n, M, &n);
+    for (size_t i = 0; i < (size_t)n * n * E; ++i) M[i] = -M[i];
+    rc = host_heevd(cplx, n, M, n, w);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) w[i] = -w[i];
+    trsm("L", "L", "C", "N", &n, &n, one, A, &n, M, &n);
+    for (int i = 0; i < n; ++i) w[i] = 1.0 / w[i];
+    for (int j = 0; j < n / 2; ++j) {
+        double s = 0.0;
+        double* col = M + (size_t)j * n * E;
+        for (int i = 0; i < n * E; ++i) s += col[i] * col[i];
+        const double inv = 1.0 / std::sqrt(s);
+        for (int i = 0; i < n * E; ++i) col[i] *= inv;
     }
     return 0;
 }

@@ -13,5 +13,7 @@ int host_heevd(bool cplx, int n, double* A, int lda, double* w);
 // symmetric tridiagonal: all eigenpairs.  d[n], e[n] (e[n-1] workspace) are destroyed.  Z is n x n column-major.
 int host_stemr(int n, double* d, double* e, double* w, double* Z, int ldz);
 int host_stedc(int n, double* d, double* e, double* w, double* Z, int ldz);   // divide & conquer, same contract
+// small dense core of the pseudo-Hermitian Rayleigh-Ritz (see host_lapack.cpp); A, M are n x n host, column-major
+int host_pseudo_rr(bool cplx, int n, double* A, double* M, double* w);
 void lapack_set_threads(int nthreads);
 }

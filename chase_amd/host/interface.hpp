@@ -52,14 +52,18 @@ public:
     void SetCholQR(bool f) { cholqr_ = f; }
     float GetDecayingRate() const { return decaying_rate_; }
     void SetDecayingRate(float r) { decaying_rate_ = r; }
+    bool UseClusterAwareDegrees() const { return cluster_aware_; }          // pseudo-Hermitian degree heuristics
+    void SetClusterAwareDegrees(bool f) { cluster_aware_ = f; }
+    float GetUpperbScaleRate() const { return upperb_scale_; }
+    void SetUpperbScaleRate(float r) { upperb_scale_ = r; }
 
 private:
     std::size_t N_, nev_, nex_;
-    bool opt_ = true, approx_ = false, cholqr_ = true;
+    bool opt_ = true, approx_ = false, cholqr_ = true, cluster_aware_ = true;
     std::size_t max_iter_ = 25, deg_extra_ = 2, num_lanczos_ = 4;
     std::size_t max_deg_ = 36, deg_ = 20, lanczos_iter_ = 25;      // fp64 defaults
     double tol_ = 1e-10;
-    float decaying_rate_ = 1.0f;
+    float decaying_rate_ = 1.0f, upperb_scale_ = 1.0f;
 };
 
 template <class T>

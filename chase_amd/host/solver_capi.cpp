@@ -11,13 +11,14 @@
 #include "algorithm.hpp"
 #include "chase_hip_impl.hpp"
 #include "pchase_hip_impl.hpp"
+#include "chase_hip_pseudo_impl.hpp"
 
 namespace chase_hip { int set_error(int code, const char* what); }
 using namespace chase_amd;
 
 using zc = std::complex<double>;
 struct chase_hip_solver {
-    int cplx = 0;
+    int cplx = 0, pseudo = 0;
     std::unique_ptr<ChaseBase<double>> d;           // ChaseHip<double> or pChaseHip<double>
     std::unique_ptr<ChaseBase<zc>> z;
     HipImplExtras* ex = nullptr;                    // same object, Impl-specific extras
@@ -64,6 +65,28 @@ int chase_hip_solver_create(chase_hip_solver** out, chase_hip_ctx* ctx, int cplx
             s->z.reset(p); s->ex = p;
         } else {
             auto* p = new ChaseHip<double>(ctx, N, nev, nex, (double*)H, ldh, (double*)V, ldv, ritzv, h_on_device != 0);
+            s->d.reset(p); s->ex = p;
+        }
+    });
+    if (rc) return rc;
+    *out = s.release();
+    return 0;
+}
+
+/* pseudo-Hermitian (BSE) sequential Impl: V is N x 2*(nev+nex), ritzv has 2*(nev+nex) entries */
+int chase_hip_solver_create_pseudo(chase_hip_solver** out, chase_hip_ctx* ctx, int cplx, size_t N, size_t nev, size_t nex,
+                                   void* H, size_t ldh, void* V, size_t ldv, double* ritzv, int h_on_device)
+{
+    if (!out || !ctx || !H || !V || !ritzv) return chase_hip::set_error(CHASE_HIP_EINVAL, "solver_create_pseudo: NULL argument");
+    auto s = std::make_unique<chase_hip_solver>();
+    s->cplx = cplx ? 1 : 0;
+    s->pseudo = 1;
+    int rc = guarded("solver_create_pseudo", [&] {
+        if (cplx) {
+            auto* p = new ChaseHipPseudo<zc>(ctx, N, nev, nex, (zc*)H, ldh, (zc*)V, ldv, ritzv, h_on_device != 0);
+            s->z.reset(p); s->ex = p;
+        } else {
+            auto* p = new ChaseHipPseudo<double>(ctx, N, nev, nex, (double*)H, ldh, (double*)V, ldv, ritzv, h_on_device != 0);
             s->d.reset(p); s->ex = p;
         }
     });
@@ -183,8 +206,14 @@ int chase_hip_solver_solve(chase_hip_solver* s, int record_trace)
     s->trace.lines.clear();
     s->trace.enabled = record_trace != 0;
     return guarded("solve", [&] {
-        if (s->cplx) Algorithm<zc, ChaseBase<zc>>::solve(s->z.get(), &s->stats, &s->trace);
-        else Algorithm<double, ChaseBase<double>>::solve(s->d.get(), &s->stats, &s->trace);
+        // chase::Solve / chase::Solve_pseudo (algorithm/algorithm.hpp:345-364)
+        if (s->pseudo) {
+            if (s->cplx) Algorithm<zc, ChaseBase<zc>>::solve_pseudo(s->z.get(), &s->stats, &s->trace);
+            else Algorithm<double, ChaseBase<double>>::solve_pseudo(s->d.get(), &s->stats, &s->trace);
+        } else {
+            if (s->cplx) Algorithm<zc, ChaseBase<zc>>::solve(s->z.get(), &s->stats, &s->trace);
+            else Algorithm<double, ChaseBase<double>>::solve(s->d.get(), &s->stats, &s->trace);
+        }
     });
 }
 
@@ -242,6 +271,19 @@ int chase_hip_op_hemm(chase_hip_solver* s, size_t block, const double* alpha, co
                        offset_left, offset_right);
         else s->d->HEMM(block, alpha[0], beta[0], offset_left, offset_right);
     });
+}
+int chase_hip_op_hemm_h2(chase_hip_solver* s, size_t block, const double* alpha, const double* beta, const double* gamma,
+                         size_t offset_left, size_t offset_right)
+{
+    return guarded("HEMM_H2", [&] {
+        if (s->cplx)
+            s->z->HEMM_H2(block, zc(alpha[0], alpha[1]), zc(beta[0], beta[1]), zc(gamma[0], gamma[1]), offset_left, offset_right);
+        else s->d->HEMM_H2(block, alpha[0], beta[0], gamma[0], offset_left, offset_right);
+    });
+}
+int chase_hip_op_kconj(chase_hip_solver* s, size_t block)
+{
+    return guarded("ApplyKconjugate", [&] { DISPATCH(s, k.ApplyKconjugate(block)); });
 }
 int chase_hip_op_qr(chase_hip_solver* s, size_t fixednev, double cond)
 {

@@ -141,6 +141,9 @@ int chase_hip_heevd(chase_hip_ctx* ctx, int cplx, int n, void* A, long lda, doub
 /* same contract; Householder tridiagonalisation + back-transformation on the GPU, tridiagonal stemr on the host
  * (chase_hip_heevd switches to it for n >= 384; env CHASE_HIP_HEEVD_GPU_MIN) */
 int chase_hip_heevd_gpu(chase_hip_ctx* ctx, int cplx, int n, void* A, long lda, double* w_host);
+/* pseudo-Hermitian (BSE) Rayleigh-Ritz: small dense part of cpu::rayleighRitz_v2 (cpu/rayleighRitz.hpp:316-383) on the host */
+int chase_hip_pseudo_rr_small(chase_hip_ctx* ctx, int cplx, int n, void* A_dev, void* M_dev, double* ritzv_host);
+int chase_hip_set_identity(chase_hip_ctx* ctx, int cplx, int n, void* A, long lda);
 int chase_hip_heevd_host(int cplx, int n, void* A_host, long lda, double* w_host); /* host-only twin (provider check) */
 /* host-only: all eigenpairs of a symmetric tridiagonal (Lanczos; lapackpp::t_stemr, cpu/lanczos.hpp:188) */
 int chase_hip_stemr_host(int n, double* d, double* e, double* w, double* Z, int ldz);

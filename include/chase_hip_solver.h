@@ -28,6 +28,11 @@ typedef struct chase_hip_stats {
  * h_on_device != 0 declares H a device pointer that is used in place. */
 int chase_hip_solver_create(chase_hip_solver** out, chase_hip_ctx* ctx, int cplx, size_t N, size_t nev, size_t nex,
                             void* H, size_t ldh, void* V, size_t ldv, double* ritzv, int h_on_device);
+/* Pseudo-Hermitian (Bethe-Salpeter) sequential Impl — ChASECPU<T, PseudoHermitianMatrix<T>> contract
+ * (Impl/chase_cpu/chase_cpu.hpp:78-97): V is N x 2*(nev+nex), ritzv holds 2*(nev+nex) values; chase_hip_solver_solve then
+ * runs chase::Solve_pseudo (algorithm/algorithm.inc:1834-2220). */
+int chase_hip_solver_create_pseudo(chase_hip_solver** out, chase_hip_ctx* ctx, int cplx, size_t N, size_t nev, size_t nex,
+                                   void* H, size_t ldh, void* V, size_t ldv, double* ritzv, int h_on_device);
 /* Distributed Impl (pChASECPU / pChASEGPU constructor contract, pchase_cpu.hpp:92-93): H_loc is this rank's DEVICE
  * block of the N x N matrix, distributed block-cyclically with (mb, nb) over the grid (mb = nb = 0: the reference's block
  * layout); the nev+nex vectors live distributed on the devices (chase_hip_psolver_{upload,download}_v move a rank's
@@ -56,6 +61,9 @@ int chase_hip_op_initvecs(chase_hip_solver* s, int random);
 int chase_hip_op_shift(chase_hip_solver* s, double c, int isunshift);
 int chase_hip_op_hemm(chase_hip_solver* s, size_t block, const double* alpha, const double* beta, size_t offset_left,
                       size_t offset_right);
+int chase_hip_op_hemm_h2(chase_hip_solver* s, size_t block, const double* alpha, const double* beta, const double* gamma,
+                         size_t offset_left, size_t offset_right);
+int chase_hip_op_kconj(chase_hip_solver* s, size_t block);
 int chase_hip_op_qr(chase_hip_solver* s, size_t fixednev, double cond);
 int chase_hip_op_rr(chase_hip_solver* s, double* ritzv, size_t block);
 int chase_hip_op_resd(chase_hip_solver* s, double* ritzv, double* resd, size_t fixednev);

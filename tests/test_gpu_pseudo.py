@@ -1,0 +1,87 @@
+"""Pseudo-Hermitian (Bethe-Salpeter) path — SURVEY.md §8 row A11 / BASELINE config 5: HEMM_H2, K-conjugation,
+S-orthogonal QR, rayleighRitz_v2 and chase::Solve_pseudo of the HIP Impl against the CPU oracle and against the reference's
+own BSE fixture (tests/chase_serial_solve_pseudo_bse_test.cpp:104-224).  GPU only."""
+import numpy as np
+import pytest
+from conftest import read_ref_matrix
+from oracle import chase_oracle as O
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(np.float64).eps
+
+
+def bse_fixture():
+    H = read_ref_matrix("cdouble_random_BSE.bin", 200, 200, True)
+    eigs = np.fromfile(__import__("os").path.join(__import__("conftest").REF_FIX, "eigs_cdouble_random_BSE.bin"),
+                       dtype=np.complex128).real
+    return H, np.sort(eigs[eigs > 0])
+
+
+def test_bse_fixture_is_pseudo_hermitian():
+    H, pos = bse_fixture()
+    S = np.diag(np.r_[np.ones(100), -np.ones(100)])
+    SH = S @ H
+    assert np.linalg.norm(SH - SH.conj().T) <= 1e-12 * np.linalg.norm(SH)
+    assert np.all(np.linalg.eigvalsh((SH + SH.conj().T) / 2) > 0)
+    assert len(pos) == 100
+
+
+def test_pseudo_operators_vs_oracle(ctx):
+    from chase_amd.capi import PseudoSolver
+    H, _ = bse_fixture()
+    nev, nex = 12, 8
+    ne = nev + nex
+    s = PseudoSolver(ctx, H, nev, nex)
+    k = O.OraclePseudoCPU(H, nev, nex)
+    s.Start(); k.Start()
+    s.initVecs(True); k.initVecs(True)
+    assert np.array_equal(s.peek_v(), k.V1)
+    s.QR(0, 1.0); k.QR(0, 1.0)
+    assert np.max(np.abs(s.peek_v() - k.V1)) < 1e-12
+    # H^2 filter steps incl. the gamma term and a column offset
+    for (a, b, g, off) in [(1e-3, 0.0, -0.2, 0), (2e-3, -0.3, -0.4, 0), (2e-3, -0.25, -0.4, 3)]:
+        s.HEMM_H2(ne, a, b, g, off); k.HEMM_H2(ne, a, b, g, off)
+    Vg, Vo = s.peek_v(), k.V1
+    assert np.max(np.abs(Vg[:, 3:ne] - Vo[:, 3:ne])) <= 1e-11 * np.abs(Vo).max()
+    s.HEMM_H2(0, 0, 0, 0, 0); k.HEMM_H2(0, 0, 0, 0, 0)           # even number of swaps
+    s.ApplyKconjugate(ne); k.ApplyKconjugate(ne)
+    Vg, Vo = s.peek_v(), k.V1
+    assert np.max(np.abs(Vg[:, ne:] - Vo[:, ne:])) <= 1e-11 * np.abs(Vo).max()
+    # K-conjugate structure: second half = [conj(lower); conj(upper)] of the first half
+    assert np.array_equal(Vg[100:, ne:], np.conj(Vg[:100, :ne])) and np.array_equal(Vg[:100, ne:], np.conj(Vg[100:, :ne]))
+    # restart from a well-conditioned K-symmetric block for QR / RR / Resd
+    s.initVecs(True); k.initVecs(True)
+    s.QR(0, 1.0); k.QR(0, 1.0)
+    s.ApplyKconjugate(ne); k.ApplyKconjugate(ne)
+    s.QR(0, 1e3); k.QR(0, 1e3)
+    assert s.get("qr_variant") == k.qr_variant
+    assert np.max(np.abs(s.peek_v() - k.V1)) < 1e-10
+    s.RR(ne, 0); k.RR(k.ritzv, ne)
+    assert np.max(np.abs(s.ritzv - k.ritzv)) <= 1e-9 * np.abs(k.ritzv).max()
+    r_g = s.Resd(0)
+    r_o = np.zeros(ne); k.Resd(k.ritzv, r_o, 0)
+    assert np.max(np.abs(r_g - r_o)) <= 1e-9 * max(1.0, r_o.max())
+    s.close()
+
+
+def test_solve_pseudo_bse_fixture(ctx):
+    """The reference's integration test: n = 200, nev = nex = 20, numLanczos = 10, lanczosIter = 50, tol 1e-10."""
+    from chase_amd.capi import PseudoSolver
+    H, pos = bse_fixture()
+    nev, nex = 20, 20
+    s = PseudoSolver(ctx, H, nev, nex)
+    s.set(tol=1e-10, deg=20, opt=1, maxiter=25, numlanczos=10, lanczositer=50)
+    st = s.solve(trace=True)
+    lam = s.ritzv[:nev].copy()
+    resid = s.resid()[:nev]
+    assert np.all(np.isfinite(lam)) and np.all(np.isfinite(resid))
+    assert np.max(resid) <= 1e-10                                         # the reference's assertion
+    V = s.V[:, :nev]
+    assert np.max(np.linalg.norm(H @ V - V * lam[None, :], axis=0)) <= 1e-10   # recomputed like the reference test
+    assert np.max(np.abs(lam - pos[:nev])) <= 1e-9                         # fixture spectrum: smallest positive eigenvalues
+    k = O.OraclePseudoCPU(H, nev, nex); k.config.num_lanczos = 10; k.config.lanczos_iter = 50
+    so = O.solve_pseudo(k)
+    assert np.max(np.abs(lam - k.ritzv[:nev])) <= 1e-9
+    assert abs(st["iterations"] - so["iterations"]) <= 1
+    assert st["locked"] >= nev
+    s.close()

@@ -103,3 +103,19 @@ def test_clement_solve_n1001():
     assert st["iterations"] < 25
     assert np.max(k.resid[:100]) < 1e-8
     assert np.max(O.residuals(H, k.ritzv[:100], k.V1[:, :100])) < 1e-8
+
+
+def test_pseudo_hermitian_oracle_on_reference_bse_fixture():
+    # tests/chase_serial_solve_pseudo_bse_test.cpp:104-224 + the fixture's reference spectrum
+    import os
+    from conftest import REF_FIX
+    H = read_ref_matrix("cdouble_random_BSE.bin", 200, 200, True)
+    eigs = np.fromfile(os.path.join(REF_FIX, "eigs_cdouble_random_BSE.bin"), dtype=np.complex128).real
+    pos = np.sort(eigs[eigs > 0])
+    k = O.OraclePseudoCPU(H, 20, 20)
+    k.config.num_lanczos, k.config.lanczos_iter = 10, 50
+    st = O.solve_pseudo(k)
+    assert st["locked"] >= 20 and st["iterations"] < 25
+    assert np.max(k.resid[:20]) <= 1e-10
+    assert np.max(O.residuals(H, k.ritzv[:20], k.V1[:, :20])) <= 1e-10
+    assert np.max(np.abs(k.ritzv[:20] - pos[:20])) <= 1e-10
