@@ -207,6 +207,8 @@ _sig("chase_hip_permute_cols", c_int, c_void_p, c_int, c_int, c_void_p, c_long, 
 _sig("chase_hip_upload_matrix", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long)
 _sig("chase_hip_download_matrix", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long)
 _sig("chase_hip_scale_rows", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_int, c_double)
+_sig("chase_hip_scale_rows_bc", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_long, c_long, c_int, c_int,
+     c_double)
 _sig("chase_hip_conj", c_int, c_void_p, c_int, c_int, c_void_p, c_long)
 _sig("chase_hip_resid_norms", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p,
      c_void_p, c_int)

@@ -207,6 +207,16 @@ int chase_hip_scale_rows(chase_hip_ctx* c, int cplx, int m, int n, void* X, long
     return 0;
 }
 
+int chase_hip_scale_rows_bc(chase_hip_ctx* c, int cplx, int m, int n, void* X, long ldx, long g0, long nb, int p, int q,
+                            double s)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "scale_rows_bc: NULL ctx");
+    if (nb <= 0 || p <= 0 || q < 0 || q >= p || (n > 0 && ldx < m)) return set_error(CHASE_HIP_EINVAL, "scale_rows_bc: bad layout");
+    const int e = ept_of(cplx);
+    KCHK(scale_rows_bc(c->stream, (double*)X, ldx * e, (long)m, n, e, g0, nb, p, q, s), "scale_rows_bc");
+    return 0;
+}
+
 int chase_hip_conj(chase_hip_ctx* c, int m, int n, void* X, long ldx)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "conj: NULL ctx");

@@ -35,6 +35,7 @@ int col_axpy(hipStream_t st, bool cplx, const double* a_dev, int a_is_real, int 
              long ldx_d, double* Y, long ldy_d, int m, int ncols);
 int col_scal(hipStream_t st, const double* a_dev, int inv, double* X, long ldx_d, long md, int ncols);
 int scale_rows(hipStream_t st, double* X, long ldx_d, long row0_d, long md, int ncols, double s);
+int scale_rows_bc(hipStream_t st, double* X, long ldx_d, long m, int ncols, int ept, long g0, long nb, int p, int q, double s);
 int conj_inplace(hipStream_t st, double* X, long ldx_d, int m, int ncols);
 int pack_upper(hipStream_t st, const double* A, long lda, int n, int ept, double* P);
 int unpack_upper(hipStream_t st, double* P, int n, int ept, double* A, long lda);

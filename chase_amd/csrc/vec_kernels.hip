@@ -248,6 +248,22 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(double* __restrict__ X,
     }
 }
 
+// rows whose GLOBAL index (1D block-cyclic: block nb, p ranks, this rank q) is >= g0: X[i, j] *= s.  The distributed
+// flipLowerHalfMatrixSign (linalg/internal/mpi/flipSign.hpp) for block and block-cyclic multivectors alike.
+// ept = doubles per element.
+__global__ __launch_bounds__(256) void scale_rows_bc_kernel(double* __restrict__ X, long ldx_d, long m, int ncols, int ept,
+                                                            long g0, long nb, int p, int q, double s)
+{
+    for (int j = blockIdx.y; j < ncols; j += gridDim.y) {
+        double* x = X + (long)j * ldx_d;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < m * ept; i += (long)gridDim.x * 256) {
+            const long l = i / ept;
+            const long g = ((l / nb) * p + q) * nb + l % nb;
+            if (g >= g0) x[i] *= s;
+        }
+    }
+}
+
 // in-place complex conjugate.  Reference: cuda/conjugate.cu:21-70
 __global__ __launch_bounds__(256) void conj_kernel(double* __restrict__ X, long ldx_d, int m, int ncols)
 {
@@ -432,6 +448,12 @@ int scale_rows(hipStream_t st, double* X, long ldx_d, long row0_d, long md, int 
 {
     if (ncols <= 0 || md <= row0_d) return 0;
     hipLaunchKernelGGL(scale_rows_kernel, grid2(md - row0_d, ncols), dim3(256), 0, st, X, ldx_d, row0_d, md, ncols, s);
+    return (int)hipGetLastError();
+}
+int scale_rows_bc(hipStream_t st, double* X, long ldx_d, long m, int ncols, int ept, long g0, long nb, int p, int q, double s)
+{
+    if (ncols <= 0 || m <= 0) return 0;
+    hipLaunchKernelGGL(scale_rows_bc_kernel, grid2(m * ept, ncols), dim3(256), 0, st, X, ldx_d, m, ncols, ept, g0, nb, p, q, s);
     return (int)hipGetLastError();
 }
 int conj_inplace(hipStream_t st, double* X, long ldx_d, int m, int ncols)

@@ -28,6 +28,8 @@ _sig("chase_hip_local_index", c_long, c_long, c_long, c_int)
 _sig("chase_hip_global_index", c_long, c_long, c_long, c_int, c_int)
 _sig("chase_hip_psolver_create", c_int, P(c_void_p), c_void_p, c_void_p, c_int, c_size_t, c_size_t, c_size_t, c_size_t,
      c_size_t, c_void_p, c_size_t, c_void_p)
+_sig("chase_hip_psolver_create_pseudo", c_int, P(c_void_p), c_void_p, c_void_p, c_int, c_size_t, c_size_t, c_size_t,
+     c_size_t, c_size_t, c_void_p, c_size_t, c_void_p)
 _sig("chase_hip_psolver_local_shape", c_int, c_void_p, P(c_size_t), P(c_size_t))
 _sig("chase_hip_psolver_upload_v", c_int, c_void_p, c_void_p, c_size_t)
 _sig("chase_hip_psolver_download_v", c_int, c_void_p, c_void_p, c_size_t)
@@ -149,15 +151,18 @@ def make_process_groups(nprow, npcol):
 
 class DistSolver:
     """pChaseHip<T> behind the C ABI (collective: every rank of the grid constructs it and calls the same methods)."""
+    _create = "chase_hip_psolver_create"
+    _colmul = 1                                   # vector columns = _colmul * (nev + nex)
 
     def __init__(self, ctx, grid, dH_loc, N, nev, nex, cplx, mb=0, nb=0, ldh=None):
         self.ctx, self.grid, self.N, self.nev, self.nex, self.cplx = ctx, grid, N, nev, nex, bool(cplx)
-        self.ritzv = np.zeros(nev + nex)
+        self.ncol = self._colmul * (nev + nex)
+        self.ritzv = np.zeros(self.ncol)
         h = c_void_p()
         ptr = dH_loc.ptr if isinstance(dH_loc, DeviceArray) else dH_loc
         ldh = ldh or (dH_loc.ld if isinstance(dH_loc, DeviceArray) else None)
-        check(lib.chase_hip_psolver_create(C.byref(h), ctx.h, grid.h, int(cplx), N, nev, nex, mb, nb, ptr, ldh,
-                                           self.ritzv.ctypes.data), "psolver_create")
+        check(getattr(lib, self._create)(C.byref(h), ctx.h, grid.h, int(cplx), N, nev, nex, mb, nb, ptr, ldh,
+                                         self.ritzv.ctypes.data), self._create)
         self.h = h
         m, n = c_size_t(), c_size_t()
         check(lib.chase_hip_psolver_local_shape(h, C.byref(m), C.byref(n)), "local_shape")
@@ -189,13 +194,13 @@ class DistSolver:
 
     def resid(self):
         p = lib.chase_hip_solver_resid(self.h)
-        return np.ctypeslib.as_array(p, shape=(self.nev + self.nex,)).copy()
+        return np.ctypeslib.as_array(p, shape=(self.ncol,)).copy()
 
     def trace(self):
         return lib.chase_hip_solver_trace(self.h).decode().splitlines()
 
     def local_V(self):
-        out = np.empty((self.m_loc, self.nev + self.nex), dtype=self.dt, order="F")
+        out = np.empty((self.m_loc, self.ncol), dtype=self.dt, order="F")
         check(lib.chase_hip_psolver_download_v(self.h, out.ctypes.data, self.m_loc), "download_v")
         return out
 
@@ -229,6 +234,19 @@ class DistSolver:
         check(lib.chase_hip_op_lanczos(self.h, M, numvec, C.byref(ub), theta.ctypes.data, tau.ctypes.data,
                                        ritzV.ctypes.data), "Lanczos")
         return ub.value, theta, tau, ritzV.reshape(M, M, order="F")
+
+
+class DistPseudoSolver(DistSolver):
+    """pChaseHipPseudo<T>: distributed pseudo-Hermitian (BSE) Impl, 2*(nev+nex) vector columns, chase::Solve_pseudo."""
+    _create = "chase_hip_psolver_create_pseudo"
+    _colmul = 2
+
+    def HEMM_H2(self, block, alpha, beta, gamma, offset_left, offset_right=0):
+        check(lib.chase_hip_op_hemm_h2(self.h, block, _z2(alpha), _z2(beta), _z2(gamma), offset_left, offset_right),
+              "HEMM_H2")
+
+    def ApplyKconjugate(self, block):
+        check(lib.chase_hip_op_kconj(self.h, block), "ApplyKconjugate")
 
 
 def local_block_of(H, rl, cl, myrow, mycol):

@@ -55,13 +55,15 @@ public:
     };
 
     // H_loc: DEVICE pointer to this rank's m_loc x n_loc block (ldh >= m_loc).  mb = nb = 0 selects the block layout.
+    // ncols: number of columns of the vector blocks (nev+nex; the pseudo-Hermitian Impl derives with 2*(nev+nex))
     pChaseHip(chase_hip_ctx* ctx, chase_hip_grid* grid, std::size_t N, std::size_t nev, std::size_t nex, std::size_t mb,
-              std::size_t nb, T* H_loc, std::size_t ldh, R* ritzv)
-        : ctx_(ctx), grid_(grid), N_(N), nev_(nev), nex_(nex), nevex_(nev + nex), dH_(H_loc), ldh_(ldh), ritzv_(ritzv),
-          config_(N, nev, nex), resid_(nev + nex, 0), perm_(nev + nex)
+              std::size_t nb, T* H_loc, std::size_t ldh, R* ritzv, std::size_t ncols = 0)
+        : ctx_(ctx), grid_(grid), N_(N), nev_(nev), nex_(nex), nevex_(nev + nex), nc_(ncols ? ncols : nev + nex),
+          dH_(H_loc), ldh_(ldh), ritzv_(ritzv), config_(N, nev, nex), resid_(ncols ? ncols : nev + nex, 0),
+          perm_(ncols ? ncols : nev + nex)
     {
         if (!ctx || !grid || !H_loc || !ritzv) throw std::invalid_argument("pChaseHip: null argument");
-        if (N == 0 || nevex_ == 0 || nevex_ > N) throw std::invalid_argument("pChaseHip: need 0 < nev+nex <= N");
+        if (N == 0 || nevex_ == 0 || nc_ > N) throw std::invalid_argument("pChaseHip: need 0 < nev+nex <= N");
         hip_ok(chase_hip_grid_info(grid, &nprow_, &npcol_, &myrow_, &mycol_), "grid_info");
         Rr_.N = Cc_.N = (long)N;
         Rr_.p = nprow_; Rr_.q = myrow_; Cc_.p = npcol_; Cc_.q = mycol_;
@@ -72,17 +74,17 @@ public:
         m_ = (std::size_t)Rr_.nloc; n_ = (std::size_t)Cc_.nloc;
         if (ldh < m_) throw std::invalid_argument("pChaseHip: ldh smaller than the local row count");
         if (m_ == 0 || n_ == 0) throw std::invalid_argument("pChaseHip: empty local block (grid too large for N)");
-        for (std::size_t i = 0; i < nevex_; ++i) perm_[i] = (int)i;
-        alloc((void**)&dV1_, m_ * nevex_ * sizeof(T));
-        alloc((void**)&dV2_, m_ * nevex_ * sizeof(T));
-        alloc((void**)&dVt_, m_ * nevex_ * sizeof(T));
-        alloc((void**)&dW1_, n_ * nevex_ * sizeof(T));
-        alloc((void**)&dW2_, n_ * nevex_ * sizeof(T));
-        alloc((void**)&dA_, nevex_ * nevex_ * sizeof(T));
-        pack_elems_ = nevex_ * nevex_ + 64 * nevex_ + 64;          // packed Gram triangle / agreement scratch
+        for (std::size_t i = 0; i < nc_; ++i) perm_[i] = (int)i;
+        alloc((void**)&dV1_, m_ * nc_ * sizeof(T));
+        alloc((void**)&dV2_, m_ * nc_ * sizeof(T));
+        alloc((void**)&dVt_, m_ * nc_ * sizeof(T));
+        alloc((void**)&dW1_, n_ * nc_ * sizeof(T));
+        alloc((void**)&dW2_, n_ * nc_ * sizeof(T));
+        alloc((void**)&dA_, 3 * nc_ * nc_ * sizeof(T));
+        pack_elems_ = nc_ * nc_ + 64 * nc_ + 64;                    // packed Gram triangle / agreement scratch
         alloc((void**)&dPack_, pack_elems_ * sizeof(T));
         // staging must hold the largest block of ANY rank (rank 0 of a dimension owns the most rows)
-        alloc((void**)&dStage_, (std::size_t)std::max(Rr_.count(0), Cc_.count(0)) * nevex_ * sizeof(T));
+        alloc((void**)&dStage_, (std::size_t)std::max(Rr_.count(0), Cc_.count(0)) * nc_ * sizeof(T));
         build_diag_lists();
         build_redistribution();
     }
@@ -94,7 +96,7 @@ public:
     std::size_t GetNex() override { return nex_; }
     std::size_t GetLanczosIter() override { return lanczosIter_; }
     std::size_t GetNumLanczos() override { return numLanczos_; }
-    std::size_t GetRitzvBlockSize() const override { return nevex_; }
+    std::size_t GetRitzvBlockSize() const override { return nc_; }
     R* GetRitzv() override { return ritzv_; }
     R* GetResid() override { return resid_.data(); }
     ConfigT& GetConfig() override { return config_; }
@@ -133,29 +135,30 @@ public:
     {
         if (random) {
             if (device_rng_) {
-                hip_ok(chase_hip_fill_normal_bc(ctx_, CP, (int)m_, (int)nevex_, dV1_, (long)m_, (long)N_, (int)Rr_.nb,
+                hip_ok(chase_hip_fill_normal_bc(ctx_, CP, (int)m_, (int)nc_, dV1_, (long)m_, (long)N_, (int)Rr_.nb,
                                                 nprow_, myrow_, 1337ull), "fill_normal_bc");
             } else {
-                std::vector<T> h(m_ * nevex_);
+                std::vector<T> h(m_ * nc_);
                 std::mt19937 gen(1337.0 + myrow_);
                 std::normal_distribution<> d;
                 for (auto& x : h) x = rnd(d, gen);
-                hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)m_, (int)nevex_, h.data(), (long)m_, dV1_, (long)m_), "upload V");
+                hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)m_, (int)nc_, h.data(), (long)m_, dV1_, (long)m_), "upload V");
             }
         }
-        hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)nevex_, dV1_, (long)m_, dV2_, (long)m_), "lacpy");
+        init_vecs_hook(random);
+        hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)nc_, dV1_, (long)m_, dV2_, (long)m_), "lacpy");
         reset_perm();
         next_bAc_ = true;
     }
     // caller-provided start vectors (approximate-solution mode): local m_loc x nevex block, host memory
     void upload_local_V(const T* host, std::size_t ldv)
     {
-        hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)m_, (int)nevex_, host, (long)ldv, dV1_, (long)m_), "upload V");
+        hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)m_, (int)nc_, host, (long)ldv, dV1_, (long)m_), "upload V");
     }
     void download_local_V(T* host, std::size_t ldv)
     {
         flush_swaps(); sync_comm();
-        hip_ok(chase_hip_download_matrix(ctx_, CP, (int)m_, (int)nevex_, dV1_, (long)m_, host, (long)ldv), "download V");
+        hip_ok(chase_hip_download_matrix(ctx_, CP, (int)m_, (int)nc_, dV1_, (long)m_, host, (long)ldv), "download V");
     }
     void End() override { flush_swaps(); sync_comm(); hip_ok(chase_hip_ctx_sync(ctx_), "sync"); }
 
@@ -281,7 +284,8 @@ public:
         hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)m, dV2_, (long)m_, dV1_, (long)m_), "lacpy");
     }
 
-private:
+protected:
+    virtual void init_vecs_hook(bool) {}            // pseudo-Hermitian Impl: damp the lower block of random start vectors
     static T rnd(std::normal_distribution<>& d, std::mt19937& g)
     {
         if constexpr (is_cplx<T>::value) { const double re = d(g); const double im = d(g); return T(re, im); }
@@ -381,14 +385,23 @@ private:
     //   cAb:  V1 = alpha * H_loc   * W1 + beta' * V1,  beta' = beta on grid col 0 only,  all-reduce over the row group
     void hemm_dir(bool bAc, std::size_t c0, std::size_t nc, T alpha, T beta, bool pipelined)
     {
+        hemm_ptr(bAc, bAc ? dV1_ : dW1_, bAc ? dW1_ : dV1_, c0, nc, alpha, beta, pipelined);
+    }
+    // in: column-type (bAc) / row-type (cAb) block, out: the other type.  For a pseudo-Hermitian H the bAc product is
+    // wrapped in sign flips of the global lower half, H V = S H^H S V (mpi/hemm.hpp:125-199); cAb is H W as it stands.
+    void hemm_ptr(bool bAc, T* in, T* out, std::size_t c0, std::size_t nc, T alpha, T beta, bool pipelined)
+    {
         const int group = bAc ? CHASE_HIP_COL : CHASE_HIP_ROW;
         const bool root = bAc ? (myrow_ == 0) : (mycol_ == 0);
         const T b = root ? beta : T(0);
         const std::size_t out_ld = bAc ? n_ : m_;
-        T* out = bAc ? dW1_ : dV1_;
-        const T* in = bAc ? dV1_ : dW1_;
         const std::size_t in_ld = bAc ? m_ : n_;
-        const bool pipe = pipelined && pipeline_ && chase_hip_grid_group_active(grid_, group) != 0;
+        const bool flip = pseudo_ && bAc;
+        const bool pipe = pipelined && pipeline_ && !flip && chase_hip_grid_group_active(grid_, group) != 0;
+        if (flip) {
+            flip_coltype(in + c0 * m_, nc);
+            if (b != T(0)) flip_rowtype(out + c0 * n_, nc);
+        }
         std::size_t c = c0;
         while (c < c0 + nc) {
             const std::size_t fp = c / PANEL;                                  // fixed panel index
@@ -401,6 +414,19 @@ private:
             if (pipe) coll(chase_hip_grid_event_record(grid_, (int)fp));
             c = cend;
         }
+        if (flip) {
+            flip_coltype(in + c0 * m_, nc);
+            flip_rowtype(out + c0 * n_, nc);
+        }
+    }
+    // X <- S X on the local rows of a column-type / row-type block (global rows >= N/2 change sign)
+    void flip_coltype(T* X, std::size_t ncols, double s = -1.0)
+    {
+        hip_ok(chase_hip_scale_rows_bc(ctx_, CP, (int)m_, (int)ncols, X, (long)m_, (long)(N_ / 2), Rr_.nb, nprow_, myrow_, s), "flip");
+    }
+    void flip_rowtype(T* X, std::size_t ncols)
+    {
+        hip_ok(chase_hip_scale_rows_bc(ctx_, CP, (int)n_, (int)ncols, X, (long)n_, (long)(N_ / 2), Cc_.nb, npcol_, mycol_, -1.0), "flip");
     }
 
     // A (n x n, Hermitian, device) <- sum over `group` of A, moving only the packed upper triangle
@@ -430,12 +456,12 @@ private:
     // mpi/cholqr.hpp:51-397 on the column-type V1 (all nevex columns); returns the agreed potrf info
     int cholqr_dist(int variant)
     {
-        const int n = (int)nevex_;
+        const int n = (int)nc_;
         const int passes = variant == 1 ? 1 : (variant == 2 ? 2 : 3);
         int info = 0;
         for (int ps = 0; ps < passes; ++ps) {
             hip_ok(chase_hip_herk(ctx_, CP, n, (int)m_, dV1_, (long)m_, dA_, (long)n), "herk");
-            allreduce_packed_upper(dA_, nevex_, CHASE_HIP_COL);
+            allreduce_packed_upper(dA_, nc_, CHASE_HIP_COL);
             if (variant == 3 && ps == 0) {
                 double nrmf = 0;
                 hip_ok(chase_hip_abs_trace(ctx_, CP, n, dA_, (long)n, &nrmf), "abs_trace");
@@ -457,32 +483,32 @@ private:
     {
         last_qr_variant_ = 0;
         T* full = nullptr;
-        int rc = chase_hip_malloc(ctx_, (void**)&full, N_ * nevex_ * sizeof(T));
+        int rc = chase_hip_malloc(ctx_, (void**)&full, N_ * nc_ * sizeof(T));
         if (rc) throw HipStatusError(rc, "householder workspace");
         try {
             for (int ip = 0; ip < nprow_; ++ip) {
                 const int cnt = rowmap_cnt_[ip];
                 if (cnt == 0) continue;
                 if (ip == myrow_)
-                    hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)nevex_, dV1_, (long)m_, dStage_, (long)m_), "lacpy");
-                coll(chase_hip_grid_bcast(grid_, CHASE_HIP_COL, dStage_, (std::size_t)cnt * nevex_ * E, ip, 0));
-                hip_ok(chase_hip_rows_indexed(ctx_, CP, dStage_, cnt, full, (long)N_, d_rowmap_[ip], cnt, (int)nevex_, 1), "scatter");
+                    hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)nc_, dV1_, (long)m_, dStage_, (long)m_), "lacpy");
+                coll(chase_hip_grid_bcast(grid_, CHASE_HIP_COL, dStage_, (std::size_t)cnt * nc_ * E, ip, 0));
+                hip_ok(chase_hip_rows_indexed(ctx_, CP, dStage_, cnt, full, (long)N_, d_rowmap_[ip], cnt, (int)nc_, 1), "scatter");
             }
-            hip_ok(chase_hip_houseqr(ctx_, CP, (int)N_, (int)nevex_, full, (long)N_), "houseqr");
-            hip_ok(chase_hip_rows_indexed(ctx_, CP, full, (long)N_, dV1_, (long)m_, d_rowmap_[myrow_], (int)m_, (int)nevex_, 0), "gather");
+            hip_ok(chase_hip_houseqr(ctx_, CP, (int)N_, (int)nc_, full, (long)N_), "houseqr");
+            hip_ok(chase_hip_rows_indexed(ctx_, CP, full, (long)N_, dV1_, (long)m_, d_rowmap_[myrow_], (int)m_, (int)nc_, 0), "gather");
             hip_ok(chase_hip_ctx_sync(ctx_), "sync");
         } catch (...) { chase_hip_free(ctx_, full); throw; }
         chase_hip_free(ctx_, full);
     }
 
-    void reset_perm() { for (std::size_t i = 0; i < nevex_; ++i) perm_[i] = (int)i; perm_dirty_ = false; }
+    void reset_perm() { for (std::size_t i = 0; i < nc_; ++i) perm_[i] = (int)i; perm_dirty_ = false; }
     // apply the deferred swaps to V1 and V2 (distMultiVector.hpp:1493 swap_ij acts on both, pchase_cpu.hpp Swap)
     void flush_swaps()
     {
         if (!perm_dirty_) return;
         sync_comm();
         std::vector<int> src, dst;
-        for (std::size_t j = 0; j < nevex_; ++j)
+        for (std::size_t j = 0; j < nc_; ++j)
             if (perm_[j] != (int)j) { src.push_back(perm_[j]); dst.push_back((int)j); }
         if (!src.empty()) {
             hip_ok(chase_hip_permute_cols(ctx_, CP, (int)m_, dV1_, (long)m_, dVt_, (long)m_, src.data(), dst.data(), (int)src.size()), "permute");
@@ -581,7 +607,7 @@ private:
 
     chase_hip_ctx* ctx_;
     chase_hip_grid* grid_;
-    std::size_t N_, nev_, nex_, nevex_;
+    std::size_t N_, nev_, nex_, nevex_, nc_;
     T* dH_; std::size_t ldh_;
     R* ritzv_;
     ConfigT config_;
@@ -592,7 +618,7 @@ private:
     Dim Rr_, Cc_;
     std::size_t m_ = 0, n_ = 0;
     std::size_t locked_ = 0, lanczosIter_ = 0, numLanczos_ = 0;
-    bool next_bAc_ = true, device_rng_ = false, pipeline_ = true;
+    bool next_bAc_ = true, device_rng_ = false, pipeline_ = true, pseudo_ = false;
     T *dV1_ = nullptr, *dV2_ = nullptr, *dVt_ = nullptr, *dW1_ = nullptr, *dW2_ = nullptr, *dA_ = nullptr;
     T *dPack_ = nullptr, *dStage_ = nullptr;
     std::size_t pack_elems_ = 0;

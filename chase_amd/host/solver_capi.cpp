@@ -12,6 +12,7 @@
 #include "chase_hip_impl.hpp"
 #include "pchase_hip_impl.hpp"
 #include "chase_hip_pseudo_impl.hpp"
+#include "pchase_hip_pseudo_impl.hpp"
 
 namespace chase_hip { int set_error(int code, const char* what); }
 using namespace chase_amd;
@@ -108,6 +109,30 @@ int chase_hip_psolver_create(chase_hip_solver** out, chase_hip_ctx* ctx, chase_h
             s->z.reset(p); s->ex = p; s->pz = p;
         } else {
             auto* p = new pChaseHip<double>(ctx, grid, N, nev, nex, mb, nb, (double*)H_loc_dev, ldh, ritzv);
+            s->d.reset(p); s->ex = p; s->pd = p;
+        }
+    });
+    if (rc) return rc;
+    *out = s.release();
+    return 0;
+}
+
+/* distributed pseudo-Hermitian (BSE) Impl: 2*(nev+nex) vector columns, ritzv has 2*(nev+nex) entries */
+int chase_hip_psolver_create_pseudo(chase_hip_solver** out, chase_hip_ctx* ctx, chase_hip_grid* grid, int cplx, size_t N,
+                                    size_t nev, size_t nex, size_t mb, size_t nb, void* H_loc_dev, size_t ldh,
+                                    double* ritzv)
+{
+    if (!out || !ctx || !grid || !H_loc_dev || !ritzv)
+        return chase_hip::set_error(CHASE_HIP_EINVAL, "psolver_create_pseudo: NULL argument");
+    auto s = std::make_unique<chase_hip_solver>();
+    s->cplx = cplx ? 1 : 0;
+    s->pseudo = 1;
+    int rc = guarded("psolver_create_pseudo", [&] {
+        if (cplx) {
+            auto* p = new pChaseHipPseudo<zc>(ctx, grid, N, nev, nex, mb, nb, (zc*)H_loc_dev, ldh, ritzv);
+            s->z.reset(p); s->ex = p; s->pz = p;
+        } else {
+            auto* p = new pChaseHipPseudo<double>(ctx, grid, N, nev, nex, mb, nb, (double*)H_loc_dev, ldh, ritzv);
             s->d.reset(p); s->ex = p; s->pd = p;
         }
     });

@@ -117,6 +117,11 @@ int chase_hip_download_matrix(chase_hip_ctx* ctx, int cplx, int m, int n, const 
                               long ldh);
 /* X[row0:, :] *= s.  Replaces cuda/flipSign.cu:19-260 (s = -1) and scaleLowerBlockRows */
 int chase_hip_scale_rows(chase_hip_ctx* ctx, int cplx, int m, int n, void* X, long ldx, int row0, double s);
+/* the same for a 1D block-cyclic row distribution (block nb over p ranks, this rank q; a block layout is nb = block
+ * length): local rows whose global index is >= g0 are scaled.  Replaces the distributed flipLowerHalfMatrixSign
+ * (linalg/internal/mpi/flipSign.hpp, cuda_aware_mpi/flipSign.hpp) and the l_half() damping of pchase_cpu.hpp:283-300 */
+int chase_hip_scale_rows_bc(chase_hip_ctx* ctx, int cplx, int m, int n, void* X, long ldx, long g0, long nb, int p, int q,
+                            double s);
 /* in-place conjugate (complex only).  Replaces cuda/conjugate.cu:21-70 */
 int chase_hip_conj(chase_hip_ctx* ctx, int m, int n, void* X, long ldx);
 /* resid[j] = ||W_j - lambda_j V_j||_2 (squared != 0: sum of squares, for the distributed all-reduce).

@@ -39,6 +39,12 @@ int chase_hip_solver_create_pseudo(chase_hip_solver** out, chase_hip_ctx* ctx, i
  * m_loc x (nev+nex) block).  All op / solve entry points below are collective over the grid. */
 int chase_hip_psolver_create(chase_hip_solver** out, chase_hip_ctx* ctx, chase_hip_grid* grid, int cplx, size_t N,
                              size_t nev, size_t nex, size_t mb, size_t nb, void* H_loc_dev, size_t ldh, double* ritzv);
+/* distributed pseudo-Hermitian (Bethe-Salpeter) Impl — mirrors pChASECPU / pChASEGPU over
+ * PseudoHermitianBlockBlockMatrix / PseudoHermitianBlockCyclicMatrix (Impl/pchase_cpu/pchase_cpu.hpp:92-190):
+ * the vector blocks have 2*(nev+nex) columns and ritzv 2*(nev+nex) entries; N must be even */
+int chase_hip_psolver_create_pseudo(chase_hip_solver** out, chase_hip_ctx* ctx, chase_hip_grid* grid, int cplx, size_t N,
+                                    size_t nev, size_t nex, size_t mb, size_t nb, void* H_loc_dev, size_t ldh,
+                                    double* ritzv);
 int chase_hip_psolver_local_shape(chase_hip_solver* s, size_t* m_loc, size_t* n_loc);
 int chase_hip_psolver_upload_v(chase_hip_solver* s, const void* host, size_t ldv);
 int chase_hip_psolver_download_v(chase_hip_solver* s, void* host, size_t ldv);

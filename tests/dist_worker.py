@@ -171,6 +171,111 @@ def scenario_solve(ctx, grid, rank, world, N, nev, nex, cplx, mb, deg):
     s.close()
 
 
+def bse_fixture():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest
+    H = conftest.read_ref_matrix("cdouble_random_BSE.bin", 200, 200, True)
+    eigs = np.fromfile(os.path.join(conftest.REF_FIX, "eigs_cdouble_random_BSE.bin"), dtype=np.complex128).real
+    return H, np.sort(eigs[eigs > 0])
+
+
+def gathered_V(s, grid, rl, world, N, dtype):
+    objs = [None] * world
+    dist.all_gather_object(objs, (grid.myrow, grid.mycol, s.local_V()))
+    V = np.zeros((N, s.ncol), dtype=dtype)
+    for (i, j, blk) in objs:
+        if j == 0:
+            V[rl.globals_of(i), :] = blk
+    # replicas over the grid columns must agree
+    for (i, j, blk) in objs:
+        assert np.array_equal(V[rl.globals_of(i), :], blk), "column-type replicas differ"
+    return V
+
+
+def scenario_pseudo_ops(ctx, grid, rank, world, mb):
+    """HEMM_H2 / ApplyKconjugate / S-orthogonal QR / rayleighRitz_v2 / Resd / pseudo Lanczos of the distributed
+    pseudo-Hermitian Impl against the serial oracle on the reference's BSE fixture."""
+    H, _ = bse_fixture()
+    N, nev, nex = 200, 12, 8
+    ne = nev + nex
+    rl, cl = cd.Layout(N, mb, grid.nprow), cd.Layout(N, mb, grid.npcol)
+    rows = rl.globals_of(grid.myrow)
+    dH = ctx.array(cd.local_block_of(H, rl, cl, grid.myrow, grid.mycol))
+    s = cd.DistPseudoSolver(ctx, grid, dH, N, nev, nex, True, mb, mb)
+    k = O.OraclePseudoCPU(H, nev, nex)
+    s.Start(); k.Start()
+    # same start block on both sides: the oracle's serial random block, damped lower half included
+    k.initVecs(True)
+    s.upload_local_V(k.V1[rows, :]); s.initVecs(False)
+    assert np.array_equal(s.local_V(), k.V1[rows, :])
+    s.QR(0, 1.0); k.QR(0, 1.0)
+    assert np.max(np.abs(s.local_V() - k.V1[rows, :])) < 1e-12
+    for (a, b, g, off) in [(1e-3, 0.0, -0.2, 0), (2e-3, -0.3, -0.4, 0), (2e-3, -0.25, -0.4, 3)]:
+        s.HEMM_H2(ne, a, b, g, off); k.HEMM_H2(ne, a, b, g, off)
+    Vg, Vo = s.local_V(), k.V1[rows, :]
+    assert np.max(np.abs(Vg[:, 3:ne] - Vo[:, 3:ne])) <= 1e-11 * np.abs(k.V1).max()
+    s.HEMM_H2(0, 0, 0, 0, 0); k.HEMM_H2(0, 0, 0, 0, 0)           # even number of buffer swaps
+    s.ApplyKconjugate(ne); k.ApplyKconjugate(ne)
+    V = gathered_V(s, grid, rl, world, N, H.dtype)
+    assert np.max(np.abs(V[:, ne:] - k.V1[:, ne:])) <= 1e-11 * np.abs(k.V1).max()
+    assert np.array_equal(V[100:, ne:], np.conj(V[:100, :ne])) and np.array_equal(V[:100, ne:], np.conj(V[100:, :ne]))
+    # well-conditioned K-symmetric block for QR / RR / Resd
+    k.initVecs(True)
+    s.upload_local_V(k.V1[rows, :]); s.initVecs(False)
+    s.QR(0, 1.0); k.QR(0, 1.0)
+    s.ApplyKconjugate(ne); k.ApplyKconjugate(ne)
+    s.QR(0, 1e3); k.QR(0, 1e3)
+    assert s.get("qr_variant") == k.qr_variant
+    assert np.max(np.abs(s.local_V() - k.V1[rows, :])) < 1e-10
+    s.RR(ne, 0); k.RR(k.ritzv, ne)
+    assert np.max(np.abs(s.ritzv - k.ritzv)) <= 1e-9 * np.abs(k.ritzv).max()
+    allv = [None] * world
+    dist.all_gather_object(allv, s.ritzv.copy())
+    assert all(np.array_equal(allv[0], a) for a in allv)
+    r_g = s.Resd(0)[:ne]
+    r_o = np.zeros(ne); k.Resd(k.ritzv, r_o, 0)
+    assert np.max(np.abs(r_g - r_o)) <= 1e-9 * max(1.0, r_o.max())
+    # locked columns take part in the S-orthogonalisation (symmetric locking layout)
+    s.ApplyKconjugate(3); k.ApplyKconjugate(3)
+    s.Lock(3); k.Lock(3)
+    s.ApplyKconjugate(ne - 3); k.ApplyKconjugate(ne - 3)         # like the driver: second half rebuilt after the filter
+    s.QR(3, 1e3); k.QR(3, 1e3)
+    assert np.max(np.abs(s.local_V() - k.V1[rows, :])) < 1e-9
+    # S-inner-product Lanczos: Ritz values of the tridiagonal matrices (4 vectors, 20 steps)
+    k2 = O.OraclePseudoCPU(H, nev, nex); k2.Start(); k2.initVecs(True)
+    s2 = cd.DistPseudoSolver(ctx, grid, dH, N, nev, nex, True, mb, mb)
+    s2.Start(); s2.upload_local_V(k2.V1[rows, :]); s2.initVecs(False)
+    _, theta, tau, _ = s2.Lanczos(20, 4)
+    _, th_o, tau_o, _ = k2.Lanczos(20, 4)
+    assert np.max(np.abs(np.sort(theta) - np.sort(np.asarray(th_o).ravel()))) <= 1e-7 * np.abs(theta).max()
+    s2.close()
+    s.close()
+
+
+def scenario_pseudo_solve(ctx, grid, rank, world, mb):
+    """chase::Solve_pseudo on the grid vs the reference's BSE integration test
+    (tests/chase_distributed_solve_pseudo_bse_test.cpp; n = 200, nev = nex = 20, numLanczos 10, lanczosIter 50)."""
+    H, pos = bse_fixture()
+    N, nev, nex = 200, 20, 20
+    rl, cl = cd.Layout(N, mb, grid.nprow), cd.Layout(N, mb, grid.npcol)
+    dH = ctx.array(cd.local_block_of(H, rl, cl, grid.myrow, grid.mycol))
+    s = cd.DistPseudoSolver(ctx, grid, dH, N, nev, nex, True, mb, mb)
+    s.set(tol=1e-10, deg=20, opt=1, maxiter=25, numlanczos=10, lanczositer=50)
+    st = s.solve()
+    lam = s.ritzv[:nev].copy()
+    resid = s.resid()[:nev]
+    assert np.all(np.isfinite(lam)) and np.all(np.isfinite(resid))
+    assert np.max(resid) <= 1e-10
+    V = gathered_V(s, grid, rl, world, N, H.dtype)[:, :nev]
+    assert np.max(np.linalg.norm(H @ V - V * lam[None, :], axis=0)) <= 1e-10
+    assert np.max(np.abs(lam - pos[:nev])) <= 1e-9
+    assert st["locked"] >= nev
+    allv = [None] * world
+    dist.all_gather_object(allv, lam)
+    assert all(np.array_equal(allv[0], a) for a in allv)
+    s.close()
+
+
 def main():
     transport, scen = sys.argv[1], sys.argv[2]
     ctx, grid, rank, world = setup(transport)
@@ -182,6 +287,10 @@ def main():
         elif scen == "solve":
             N, nev, nex = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
             scenario_solve(ctx, grid, rank, world, N, nev, nex, sys.argv[6] == "z", int(sys.argv[7]), int(sys.argv[8]))
+        elif scen == "pseudo_ops":
+            scenario_pseudo_ops(ctx, grid, rank, world, int(sys.argv[3]))
+        elif scen == "pseudo_solve":
+            scenario_pseudo_solve(ctx, grid, rank, world, int(sys.argv[3]))
         else:
             raise SystemExit("unknown scenario " + scen)
         dist.barrier()

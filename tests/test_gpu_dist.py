@@ -50,3 +50,18 @@ def test_solve_rccl_forced_through_size1_communicators(monkeypatch):
     monkeypatch.setenv("CHASE_HIP_RCCL_FORCE", "1")
     run_ranks(1, "rccl", "solve", 1001, 100, 60, "z", 64, 20)
     run_ranks(1, "rccl", "ops", "d", 0)
+
+
+# ---- distributed pseudo-Hermitian (BSE) Impl: BASELINE config 5 / SURVEY.md §8 A11 ------------------------------------
+@pytest.mark.parametrize("nranks,mb", [(2, 0), (4, 0), (4, 16), (6, 0)])
+def test_pseudo_operators_vs_oracle(nranks, mb):
+    run_ranks(nranks, "host", "pseudo_ops", mb)
+
+
+@pytest.mark.parametrize("nranks,mb", [(4, 0), (4, 32), (2, 0)])
+def test_pseudo_solve_bse_fixture(nranks, mb):
+    run_ranks(nranks, "host", "pseudo_solve", mb)
+
+
+def test_pseudo_solve_rccl_single_rank():
+    run_ranks(1, "rccl", "pseudo_solve", 0)
