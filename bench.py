@@ -41,7 +41,12 @@ WORKLOADS = {
     "cfg2": (16384, True, 512, 128),
     "cfg3": (32768, False, 1024, 256),
     "cfg4": (65536, True, 2048, 512),
+    # BASELINE configs[4]: pseudo-Hermitian Bethe-Salpeter, chase::Solve_pseudo, nex = nev/4 like the other configurations;
+    # synthetic matrix chase_hip_gen_bse (dmin 1, dmax 11, off-diagonal 1e-3 N(0,1)); always runs the grid Impl
+    "cfg5": (32768, True, 256, 64),
 }
+PSEUDO_WORKLOADS = {"cfg5"}
+BSE_MATRIX = {"dmin": 1.0, "dmax": 11.0, "offdiag": 1e-3}
 
 
 def cpu_baseline(N, cplx, ncols, budget_s=25.0):
@@ -158,6 +163,20 @@ def main():
                     help="block size of a block-cyclic H distribution (0 = block layout, -1 = the workload's default)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.workload in PSEUDO_WORKLOADS and world == 1 and args.gpus <= 1:
+        # the pseudo-Hermitian workload runs the grid Impl on a 1x1 grid (communicator-free) when launched directly
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("LOCAL_RANK", "0")
+        os.environ["WORLD_SIZE"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(port))
+        args.gpus = 1
+        world = 1
+        from chase_amd.dist_bench import run_distributed
+        print(json.dumps(run_distributed(args)), flush=True)
+        return
     if args.gpus > 1 or world > 1:
         from chase_amd.dist_bench import run_distributed
         out = run_distributed(args)

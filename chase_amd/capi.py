@@ -178,6 +178,13 @@ class Context:
                                         float(perturb), seed), "gen_clement")
         return dH
 
+    def gen_bse(self, N, cplx=True, dmin=1.0, dmax=11.0, offdiag=1e-3, seed=7):
+        """Whole N x N synthetic Bethe-Salpeter matrix generated in HBM (see chase_hip_gen_bse)."""
+        dH = self.empty((N, N), np.complex128 if cplx else np.float64)
+        check(lib.chase_hip_gen_bse(self.h, int(cplx), dH.ptr, N, N, N, N, N, 1, 0, N, 1, 0, float(dmin), float(dmax),
+                                    float(offdiag), seed), "gen_bse")
+        return dH
+
     def mfma_f64_peak(self):
         t = c_double()
         check(lib.chase_hip_mfma_f64_peak(self.h, C.byref(t)), "mfma_f64_peak")
@@ -198,6 +205,8 @@ _sig("chase_hip_fill_normal", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_
      C.c_ulonglong)
 _sig("chase_hip_gen_clement", c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_int, c_long, c_int, c_int, c_int,
      c_long, c_int, c_int, c_int, c_long, c_double, c_double, C.c_ulonglong)
+_sig("chase_hip_gen_bse", c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_int, c_long, c_int, c_int, c_int, c_int, c_int,
+     c_int, c_double, c_double, c_double, C.c_ulonglong)
 _sig("chase_hip_shift_diag", c_int, c_void_p, c_int, c_int, c_void_p, c_long, c_double)
 _sig("chase_hip_shift_list", c_int, c_void_p, c_int, c_void_p, c_long, c_void_p, c_void_p, c_int, c_double)
 _sig("chase_hip_lacpy", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long)

@@ -118,6 +118,17 @@ int chase_hip_gen_clement(chase_hip_ctx* c, int cplx, void* H, long ldh, int mlo
     return 0;
 }
 
+int chase_hip_gen_bse(chase_hip_ctx* c, int cplx, void* H, long ldh, int mloc, int nloc, long N, int mb, int pr, int pi,
+                      int nb, int pc, int pj, double dmin, double dmax, double offdiag, unsigned long long seed)
+{
+    if (!c || !H) return set_error(CHASE_HIP_EINVAL, "gen_bse: NULL argument");
+    if (mloc < 0 || nloc < 0 || ldh < mloc || mb <= 0 || nb <= 0 || pr <= 0 || pc <= 0 || N <= 0 || N % 2)
+        return set_error(CHASE_HIP_EINVAL, "gen_bse: bad shape (N must be even)");
+    KCHK(gen_bse(c->stream, cplx != 0, (double*)H, ldh, mloc, nloc, N, mb, pr, pi, nb, pc, pj, dmin, dmax, offdiag, seed),
+         "gen_bse");
+    return 0;
+}
+
 int chase_hip_shift_diag(chase_hip_ctx* c, int cplx, int n, void* H, long ldh, double shift)
 {
     if (!c || (!H && n > 0)) return set_error(CHASE_HIP_EINVAL, "shift_diag: NULL argument");

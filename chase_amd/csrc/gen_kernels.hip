@@ -98,6 +98,53 @@ __global__ __launch_bounds__(256) void gen_clement_kernel(double* __restrict__ H
     }
 }
 
+// Synthetic Bethe-Salpeter matrix H = [[A, B], [-conj(B), -conj(A)]] of order N = 2h, any 2D shard (the reference's BSE
+// benchmark reads such a matrix from a file, examples/5_bse_benchmark/5_bse_benchmark.cpp; its test fixture
+// tests/linalg/internal/BSE_matrices/cdouble_random_BSE.bin has the same block structure):
+//   A Hermitian:  A[i,i] = sqrt(dmin^2 + (dmax^2 - dmin^2) * i / (h - 1))  (eigenvalues of H^2, which the filter sees,
+//                 spread uniformly),  A[i,j] = offdiag * (g0 + i g1) for i < j, conj below
+//   B symmetric:  B[i,j] = B[j,i] = offdiag * (g2 + i g3)
+// g ~ N(0,1) keyed on the unordered pair, so every shard sees the same global matrix.  S H = [[A, B], [conj(B), conj(A)]]
+// is Hermitian, and positive definite when dmin > ~2 offdiag sqrt(N).  Real build: A, B real symmetric.
+template <bool CPLX>
+__global__ __launch_bounds__(256) void gen_bse_kernel(double* __restrict__ H, long ldh, int mloc, int nloc, long N, int mb,
+                                                      int pr, int pi, int nb, int pc, int pj, double dmin, double dmax,
+                                                      double offdiag, unsigned long long seed)
+{
+    const long h = N / 2;
+    for (int j = blockIdx.y; j < nloc; j += gridDim.y) {
+        const long gj = ((long)(j / nb) * pc + pj) * nb + j % nb;
+        const bool bj = gj >= h;
+        const long jj = bj ? gj - h : gj;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < mloc; i += gridDim.x * 256) {
+            const long gi = ((long)(i / mb) * pr + pi) * mb + i % mb;
+            const bool bi = gi >= h;
+            const long ii = bi ? gi - h : gi;
+            const long lo = ii < jj ? ii : jj, hi = ii < jj ? jj : ii;
+            const unsigned long long key = (unsigned long long)lo * (unsigned long long)h + (unsigned long long)hi;
+            double re, im = 0.0;
+            if (bi == bj) {                                    // +-A (diagonal blocks)
+                if (ii == jj) re = sqrt(dmin * dmin + (h > 1 ? (dmax * dmax - dmin * dmin) * (double)ii / (double)(h - 1) : 0.0));
+                else {
+                    double z0, z1;
+                    normal_pair(key, seed, z0, z1);
+                    re = offdiag * z0;
+                    im = (ii < jj) ? offdiag * z1 : -offdiag * z1;
+                }
+                if (bi) re = -re;                              // -conj(a) = -re + i im
+            } else {                                           // B (upper right) / -conj(B) (lower left)
+                double z0, z1;
+                normal_pair(key, seed ^ 0x9e3779b97f4a7c15ull, z0, z1);
+                re = offdiag * z0;
+                im = offdiag * z1;
+                if (bi) re = -re;                              // -conj(b) = -re + i im
+            }
+            if constexpr (CPLX) { double* p = H + ((long)j * ldh + i) * 2; p[0] = re; p[1] = im; }
+            else H[(long)j * ldh + i] = re;
+        }
+    }
+}
+
 static inline dim3 grid_for(int m, int n)
 {
     unsigned gx = (unsigned)((m + 1023) / 1024); if (gx < 1) gx = 1; if (gx > 64) gx = 64;
@@ -120,6 +167,15 @@ int gen_clement(hipStream_t st, bool cplx, double* H, long ldh, int mloc, int nl
     if (mloc <= 0 || nloc <= 0) return 0;
     if (cplx) hipLaunchKernelGGL(gen_clement_kernel<true>, grid_for(mloc, nloc), dim3(256), 0, st, H, ldh, mloc, nloc, N, mb, pr, pi, roff, nb, pc, pj, coff, scale, perturb, seed);
     else      hipLaunchKernelGGL(gen_clement_kernel<false>, grid_for(mloc, nloc), dim3(256), 0, st, H, ldh, mloc, nloc, N, mb, pr, pi, roff, nb, pc, pj, coff, scale, perturb, seed);
+    return (int)hipGetLastError();
+}
+
+int gen_bse(hipStream_t st, bool cplx, double* H, long ldh, int mloc, int nloc, long N, int mb, int pr, int pi, int nb,
+            int pc, int pj, double dmin, double dmax, double offdiag, unsigned long long seed)
+{
+    if (mloc <= 0 || nloc <= 0) return 0;
+    if (cplx) hipLaunchKernelGGL(gen_bse_kernel<true>, grid_for(mloc, nloc), dim3(256), 0, st, H, ldh, mloc, nloc, N, mb, pr, pi, nb, pc, pj, dmin, dmax, offdiag, seed);
+    else      hipLaunchKernelGGL(gen_bse_kernel<false>, grid_for(mloc, nloc), dim3(256), 0, st, H, ldh, mloc, nloc, N, mb, pr, pi, nb, pc, pj, dmin, dmax, offdiag, seed);
     return (int)hipGetLastError();
 }
 

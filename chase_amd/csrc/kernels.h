@@ -47,6 +47,8 @@ int fill_normal(hipStream_t st, bool cplx, double* X, long ldx, int m, int n, lo
                 unsigned long long seed, int mb = 0, int pr = 1, int pi = 0);
 int gen_clement(hipStream_t st, bool cplx, double* H, long ldh, int mloc, int nloc, long N, int mb, int pr, int pi,
                 long roff, int nb, int pc, int pj, long coff, double scale, double perturb, unsigned long long seed);
+int gen_bse(hipStream_t st, bool cplx, double* H, long ldh, int mloc, int nloc, long N, int mb, int pr, int pi, int nb,
+            int pc, int pj, double dmin, double dmax, double offdiag, unsigned long long seed);
 
 // ---- factorisation cores (factor_kernels.hip) ----
 int potf2_trtri(hipStream_t st, bool cplx, double* A, long lda, int nb, int joff, double* Tinv, int* info_dev);

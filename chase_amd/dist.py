@@ -261,3 +261,12 @@ def gen_clement_local(ctx, N, cplx, rl, cl, myrow, mycol, scale=1.0, perturb=0.0
     check(lib.chase_hip_gen_clement(ctx.h, int(cplx), dH.ptr, m, m, n, N, rl.nb, rl.p, myrow, 0, cl.nb, cl.p, mycol, 0,
                                     float(scale), float(perturb), seed), "gen_clement")
     return dH
+
+
+def gen_bse_local(ctx, N, cplx, rl, cl, myrow, mycol, dmin=1.0, dmax=11.0, offdiag=1e-3, seed=7):
+    """This rank's shard of the synthetic Bethe-Salpeter matrix (BASELINE config 5), generated in HBM."""
+    m, n = rl.count(myrow), cl.count(mycol)
+    dH = ctx.empty((m, n), np.complex128 if cplx else np.float64)
+    check(lib.chase_hip_gen_bse(ctx.h, int(cplx), dH.ptr, m, m, n, N, rl.nb, rl.p, myrow, cl.nb, cl.p, mycol,
+                                float(dmin), float(dmax), float(offdiag), seed), "gen_bse")
+    return dH

@@ -32,10 +32,17 @@ def run_distributed(args):
     grid = cd.Grid(ctx, nprow, npcol, rank, transport=os.environ.get("CHASE_HIP_TRANSPORT", "rccl"), pg=pg)
     mb = nb = args.block_cyclic if args.block_cyclic >= 0 else B.DEFAULT_BLOCK_CYCLIC.get(workload, 0)
     rl, cl = cd.Layout(N, mb, nprow), cd.Layout(N, nb, npcol)
-    dH = cd.gen_clement_local(ctx, N, cplx, rl, cl, myrow, mycol, scale=B.MATRIX_SCALE / N, perturb=B.MATRIX_PERTURB)
-    ctx.sync()
-    s = cd.DistSolver(ctx, grid, dH, N, nev, nex, cplx, mb, nb)
-    s.set(device_rng=1)
+    pseudo = workload in B.PSEUDO_WORKLOADS
+    if pseudo:
+        dH = cd.gen_bse_local(ctx, N, cplx, rl, cl, myrow, mycol, **B.BSE_MATRIX)
+        ctx.sync()
+        s = cd.DistPseudoSolver(ctx, grid, dH, N, nev, nex, cplx, mb, nb)
+        s.set(device_rng=1, numlanczos=10, lanczositer=50)      # the reference's BSE settings (5_bse_benchmark / BSE test)
+    else:
+        dH = cd.gen_clement_local(ctx, N, cplx, rl, cl, myrow, mycol, scale=B.MATRIX_SCALE / N, perturb=B.MATRIX_PERTURB)
+        ctx.sync()
+        s = cd.DistSolver(ctx, grid, dH, N, nev, nex, cplx, mb, nb)
+        s.set(device_rng=1)
     F = 4 if cplx else 1
     for _ in range(args.warmup):
         s.set(reset_counters=1)
@@ -70,7 +77,9 @@ def run_distributed(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if args.workload else "weak", "vs_baseline": None,
             "dtype": "complex f64" if cplx else "f64", "data": "synthetic",
-            "config": {"workload": f"{workload}: ChASE solve, perturbed Clement-type Hermitian (x100/N) N={N} "
+            "config": {"workload": f"{workload}: ChASE solve, "
+                                   + ("synthetic Bethe-Salpeter pseudo-Hermitian (Solve_pseudo, H^2 filter)" if pseudo
+                                      else "perturbed Clement-type Hermitian (x100/N)") + f" N={N} "
                                    f"{'complex' if cplx else 'real'} fp64, nev={nev} nex={nex}, tol 1e-10, deg 20 opt, "
                                    f"{nprow}x{npcol} {'block-cyclic nb=%d' % nb if nb else 'block'} grid, RCCL",
                        "N": N, "nev": nev, "nex": nex, "grid": f"{nprow}x{npcol}"},

@@ -134,7 +134,10 @@ public:
         std::size_t ncols = (offset_right < block) ? block - offset_right : 0;
         if (ncols != 0) {
             const std::size_t c0 = offset_left + locked_;
-            if (c0 + ncols > nc_) ncols = nc_ - c0;     // the reference's call runs past the first half; clamp to the buffer
+            // the reference's filter call runs `block` columns from c0, i.e. past the first half into second-half columns
+            // that ApplyKconjugate overwrites right after the filter (algorithm.inc:1012-1064): stop at the first half
+            if (c0 >= nevex_) { std::swap(dV1_, dV2_); return; }
+            if (c0 + ncols > nevex_) ncols = nevex_ - c0;
             T* v1 = dV1_ + c0 * N_;
             T* v2 = dV2_ + c0 * N_;
             gemm('N', N_, ncols, N_, T(1), dH_, ldd_h_, v1, N_, T(0), dTmp_, N_);

@@ -59,7 +59,10 @@ public:
         std::size_t ncols = (offset_right < block) ? block - offset_right : 0;
         if (ncols != 0) {
             const std::size_t c0 = offset_left + this->locked_, m = this->m_;
-            if (c0 + ncols > this->nc_) ncols = this->nc_ - c0;
+            // the reference's filter call runs `block` columns from c0, i.e. past the first half into second-half columns
+            // that ApplyKconjugate overwrites right after the filter (algorithm.inc:1012-1064): stop at the first half
+            if (c0 >= this->nevex_) { std::swap(this->dV1_, this->dV2_); return; }
+            if (c0 + ncols > this->nevex_) ncols = this->nevex_ - c0;
             this->hemm_ptr(true, this->dV1_, this->dW1_, c0, ncols, T(1), T(0), false);      // W1 = H V1   (row-type)
             this->hemm_ptr(false, this->dW1_, this->dV2_, c0, ncols, alpha, beta, false);    // V2 = alpha H W1 + beta V2
             upload_scalar(gamma);

@@ -89,6 +89,11 @@ int chase_hip_rows_indexed(chase_hip_ctx* ctx, int cplx, const void* in, long ld
 int chase_hip_gen_clement(chase_hip_ctx* ctx, int cplx, void* H, long ldh, int mloc, int nloc, long N, int mb, int pr,
                           int pi, long roff, int nb, int pc, int pj, long coff, double scale, double perturb,
                           unsigned long long seed);
+/* Synthetic Bethe-Salpeter test matrix H = [[A, B], [-conj(B), -conj(A)]] (A Hermitian with diagonal dmin..dmax spaced uniformly in
+ * the square, B symmetric, off-diagonal entries offdiag * N(0,1)), any 2D block-cyclic shard; stands in for the matrix file of
+ * examples/5_bse_benchmark/5_bse_benchmark.cpp (BASELINE config 5) */
+int chase_hip_gen_bse(chase_hip_ctx* ctx, int cplx, void* H, long ldh, int mloc, int nloc, long N, int mb, int pr, int pi,
+                      int nb, int pc, int pj, double dmin, double dmax, double offdiag, unsigned long long seed);
 
 /* ---- host LAPACK provider (HEEVD / STEMR stay on the host per the north star) --------------------------------- */
 int chase_hip_set_lapack_lib(const char* path);   /* optional explicit LP64 LAPACK shared library */

@@ -85,3 +85,48 @@ def test_solve_pseudo_bse_fixture(ctx):
     assert abs(st["iterations"] - so["iterations"]) <= 1
     assert st["locked"] >= nev
     s.close()
+
+
+def test_gen_bse_structure_and_shards(ctx):
+    """chase_hip_gen_bse: H = [[A, B], [-conj(B), -conj(A)]], S H Hermitian positive definite; block-cyclic shards
+    generated independently equal the corresponding entries of the whole matrix."""
+    from chase_amd import dist as cd
+    N, h = 96, 48
+    H = ctx.gen_bse(N, True, dmin=1.0, dmax=5.0, offdiag=1e-2, seed=11).download()
+    A, B = H[:h, :h], H[:h, h:]
+    assert np.array_equal(A, A.conj().T) and np.array_equal(B, B.T)
+    assert np.array_equal(H[h:, :h], -B.conj()) and np.array_equal(H[h:, h:], -A.conj())
+    assert np.allclose(np.diag(A).real, np.sqrt(1.0 + 24.0 * np.arange(h) / (h - 1)), rtol=0, atol=1e-14)
+    SH = np.vstack([H[:h], -H[h:]])
+    assert np.linalg.norm(SH - SH.conj().T) == 0 and np.linalg.eigvalsh(SH).min() > 0.5
+    off = A[np.triu_indices(h, 1)]
+    assert 0.5e-2 < off.real.std() < 2e-2 and 0.5e-2 < off.imag.std() < 2e-2
+    for (mb, pr, pc) in [(0, 2, 2), (8, 3, 2)]:
+        rl, cl = cd.Layout(N, mb, pr), cd.Layout(N, mb, pc)
+        for i in range(pr):
+            for j in range(pc):
+                blk = cd.gen_bse_local(ctx, N, True, rl, cl, i, j, dmin=1.0, dmax=5.0, offdiag=1e-2, seed=11).download()
+                assert np.array_equal(blk, H[np.ix_(rl.globals_of(i), cl.globals_of(j))])
+    Hr = ctx.gen_bse(N, False, dmin=1.0, dmax=5.0, offdiag=1e-2, seed=11).download()
+    assert np.array_equal(Hr[:h, :h], Hr[:h, :h].T) and np.array_equal(Hr[h:, h:], -Hr[:h, :h])
+    assert np.array_equal(Hr[h:, :h], -Hr[:h, h:])
+
+
+def test_solve_pseudo_generated_bse_vs_oracle(ctx):
+    """Solve_pseudo on the synthetic BSE matrix of the benchmark family (N = 400) against the oracle and numpy."""
+    from chase_amd.capi import PseudoSolver
+    N, nev, nex = 400, 16, 10
+    H = np.asfortranarray(ctx.gen_bse(N, True, dmin=1.0, dmax=11.0, offdiag=1e-3, seed=7).download())
+    s = PseudoSolver(ctx, H, nev, nex)
+    s.set(tol=1e-10, numlanczos=10, lanczositer=50)
+    st = s.solve()
+    lam = s.ritzv[:nev].copy()
+    ev = np.linalg.eigvals(H).real
+    pos = np.sort(ev[ev > 0])
+    assert np.max(np.abs(np.sort(lam) - pos[:nev])) <= 1e-9
+    assert np.max(s.resid()[:nev]) <= 1e-10
+    k = O.OraclePseudoCPU(H, nev, nex); k.config.num_lanczos = 10; k.config.lanczos_iter = 50
+    so = O.solve_pseudo(k)
+    assert np.max(np.abs(np.sort(lam) - np.sort(k.ritzv[:nev]))) <= 1e-9
+    assert abs(st["iterations"] - so["iterations"]) <= 1
+    s.close()
