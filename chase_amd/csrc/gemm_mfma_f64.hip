@@ -11,7 +11,9 @@
 //   * back-transform             V = Q*A                    (reference: linalg/internal/cpu/rayleighRitz.hpp:110)
 //
 // Design (MI355X-first, not a translation of any CUDA tiling):
-//   * v_mfma_f64_16x16x4_f64, one 64-lane wave owns a (16*TM) x (16*TN) output tile, 4 waves (2x2) per workgroup.
+//   * v_mfma_f64_16x16x4_f64, one 64-lane wave owns a (16*TM) x (16*TN) output tile; the 4 waves of a workgroup are
+//     stacked along M (4x1) and each spans the tile's whole width, so skipping the 16-column groups of a ragged last
+//     column tile unloads all four SIMDs alike.
 //     MFMA operand roles are swapped (first operand = B/V fragment, second = A/H fragment) so that the accumulator's
 //     lane index runs along the column-major M direction -> 256-byte contiguous C stores per 16 lanes.
 //   * Everything in LDS is addressed in 16-byte "units" so that every fragment fetch is one ds_read_b128 and the
@@ -44,9 +46,11 @@ typedef d2_t d2u_t __attribute__((aligned(8)));   // 16-byte vector that may sit
 template <bool CPLX, bool OPA_C>
 struct Cfg {
     static constexpr int NTHREADS = 256;
-    static constexpr int WAVES_M = 2, WAVES_N = 2;
-    static constexpr int TM = 4;                    // 16-row MFMA tiles per wave along M
-    static constexpr int TN = CPLX ? 2 : 4;         // 16-col MFMA tiles per wave along N
+    // the 4 waves are stacked along M and every wave spans the tile's whole width, so the 16-column groups a
+    // ragged last column tile does not need are skipped by all four waves alike (balanced over the 4 SIMDs)
+    static constexpr int WAVES_M = 4, WAVES_N = 1;
+    static constexpr int TM = 2;                    // 16-row MFMA tiles per wave along M
+    static constexpr int TN = CPLX ? 4 : 8;         // 16-col MFMA tiles per wave along N
     static constexpr int BM = 16 * TM * WAVES_M;    // 128
     static constexpr int BN = 16 * TN * WAVES_N;    // 128 (real) / 64 (complex)
     static constexpr int BK = CPLX ? 8 : 16;        // elements of T along K per stage
@@ -96,7 +100,9 @@ struct GemmArgs {
 
 // TAG only changes the symbol name: TAG = 1 is the instantiation launched between FilterPhaseStart/End, so that
 // rocprofv3 --kernel-trace --stats reports the Chebyshev-filter HEMM separately from the QR / RR / residual products.
-template <bool CPLX, bool OPA_C, int TAG>
+// RAGGED: the launch covers a column range whose (single) last column tile needs fewer than TN 16-column groups; only
+// that instantiation carries the per-group branches (the whole-tile one keeps its MFMA clusters branch-free).
+template <bool CPLX, bool OPA_C, int TAG, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
 {
     using C_ = Cfg<CPLX, OPA_C>;
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;        // wave position in the 2x2 grid
+    const int wm = wave % C_::WAVES_M, wn = wave / C_::WAVES_M;     // wave position in the WAVES_M x WAVES_N grid
     const int c16 = lane & 15, q = lane >> 4;
 
     // ---- logical tile -------------------------------------------------------------------------------------------
@@ -231,8 +237,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
 
     const int wrow = wm * (16 * TM);                // wave's first row inside the block tile
     const int wcol = wn * (16 * TN);
+    // ragged last column tile: 16-column groups past n carry no MFMAs (wave-uniform count, 0..TN), so a partial tile
+    // costs what its valid columns cost and the freed matrix-core time goes to the co-resident workgroup
+    const int jv = RAGGED ? __builtin_amdgcn_readfirstlane(min(TN, max(0, (p.n - col0 - wcol + 15) >> 4))) : TN;
 
-    auto compute = [&](int stage) {
+    auto compute = [&](int stage) __attribute__((always_inline)) {
+        constexpr bool FULL = !RAGGED;                        // FULL: every 16-column group is live (no per-group branches)
         const d2_t* sA = lds + stage * C_::STAGE_UNITS;
         const d2_t* sB = sA + C_::A_UNITS;
         if constexpr (CPLX) {
@@ -264,6 +274,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                 for (int j = 0; j < TN; ++j) nb[j] = OPA_C ? -fb[ch][j].x : -fb[ch][j].y;
                 #pragma unroll
                 for (int j = 0; j < TN; ++j)
+                    if (FULL || j < jv)
                     #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ch][j].x, fa[ch][i].x, acc[0][j][i], 0, 0, 0);
@@ -271,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                     }
                 #pragma unroll
                 for (int j = 0; j < TN; ++j)
+                    if (FULL || j < jv)
                     #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(OPA_C ? fb[ch][j].y : nb[j], fa[ch][i].y, acc[0][j][i], 0, 0, 0);
@@ -311,6 +323,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                 for (int s = 0; s < 2; ++s)
                     #pragma unroll
                     for (int j = 0; j < TN; ++j)
+                        if (FULL || j < jv)
                         #pragma unroll
                         for (int i = 0; i < TM; ++i)
                             acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(
@@ -318,7 +331,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
             }
         }
     };
-
     // ---- main loop ----------------------------------------------------------------------------------------------
     bool done = false;
     {
@@ -331,36 +343,57 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
         // never stored), only a ragged M edge needs the guarded register path
         if ((row0 + BM <= p.m) && nfull >= 1 && p.glds_ok) {
             const int wv = __builtin_amdgcn_readfirstlane(wave);
-            auto issue = [&](int k0, int stage) {
-                d2_t* sA = lds + stage * C_::STAGE_UNITS;
+            // Source addresses = wave-uniform 64-bit base (SGPRs, advanced by a constant stride per K step with two scalar
+            // adds) + a per-lane 32-bit byte offset that never changes: no 64-bit vector arithmetic or multiplies in the
+            // loop.  The LDS stage cycles through a running counter.
+            constexpr int NA = C_::A_GLDS / 4, NB = C_::B_GLDS / 4;
+            const char* sa[NA];                                 // uniform
+            unsigned va[NA];                                    // per lane, bytes
+            const char* sb = (const char*)(p.B + ((long)col0 * p.ldb + kbeg) * EPT);
+            unsigned vb[NB];
+            #pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const int t = wv * NA + u;
+                if constexpr (!OPA_C) {
+                    // [k][unit] image: complex 128 units per k row (two instructions), real 64 units (one)
+                    const int kk = CPLX ? (t >> 1) : t, half = CPLX ? (t & 1) : 0;
+                    sa[u] = (const char*)(p.A + ((long)(kbeg + kk) * p.lda + row0) * EPT + (long)half * 128);
+                    va[u] = (unsigned)lane * 16u;
+                } else {
+                    const int r = 8 * t + (lane >> 3), ku = (lane & 7) ^ ((r >> 1) & 7);
+                    sa[u] = (const char*)(p.A + ((long)row0 * p.lda + kbeg) * EPT);
+                    va[u] = (unsigned)(((long)r * p.lda + ku * KPU) * EPT * 8);
+                }
+            }
+            #pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int t = wv * NB + u;
+                const int r = 8 * t + (lane >> 3), ku = (lane & 7) ^ ((r >> 1) & 7);
+                const int rc = min(r, p.n - 1 - col0);          // rows past n re-read the last valid column
+                vb[u] = (unsigned)(((long)rc * p.ldb + ku * KPU) * EPT * 8);
+            }
+            const long stepA = (OPA_C ? (long)BK * EPT : (long)BK * p.lda * EPT) * 8;
+            constexpr long stepB = (long)BK * EPT * 8;
+            int st_issue = 0;                                   // stage the next issue() fills
+            auto issue = [&]() __attribute__((always_inline)) {
+                d2_t* sA = lds + st_issue * C_::STAGE_UNITS;
                 d2_t* sB = sA + C_::A_UNITS;
                 #pragma unroll
-                for (int u = 0; u < C_::A_GLDS / 4; ++u) {
-                    const int t = wv * (C_::A_GLDS / 4) + u;
-                    const double* g;
-                    if constexpr (!OPA_C) {
-                        // [k][unit] image: complex 128 units per k row (two instructions), real 64 units (one)
-                        const int kk = CPLX ? (t >> 1) : t, half = CPLX ? (t & 1) : 0;
-                        g = p.A + ((long)(k0 + kk) * p.lda + row0) * EPT + (long)(half * 64 + lane) * 2;
-                    } else {
-                        const int r = 8 * t + (lane >> 3), ku = (lane & 7) ^ ((r >> 1) & 7);
-                        g = p.A + ((long)(row0 + r) * p.lda + k0 + ku * KPU) * EPT;
-                    }
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                                     (__attribute__((address_space(3))) void*)(sA + t * 64), 16, 0, 0);
+                for (int u = 0; u < NA; ++u) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sa[u] + (size_t)va[u]),
+                                                     (__attribute__((address_space(3))) void*)(sA + (wv * NA + u) * 64), 16, 0, 0);
+                    sa[u] += stepA;
                 }
                 #pragma unroll
-                for (int u = 0; u < C_::B_GLDS / 4; ++u) {
-                    const int t = wv * (C_::B_GLDS / 4) + u;
-                    const int r = 8 * t + (lane >> 3), ku = (lane & 7) ^ ((r >> 1) & 7);
-                    const int gc = min(col0 + r, p.n - 1);
-                    const double* g = p.B + ((long)gc * p.ldb + k0 + ku * KPU) * EPT;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                                     (__attribute__((address_space(3))) void*)(sB + t * 64), 16, 0, 0);
-                }
+                for (int u = 0; u < NB; ++u)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + (size_t)vb[u]),
+                                                     (__attribute__((address_space(3))) void*)(sB + (wv * NB + u) * 64), 16, 0, 0);
+                sb += stepB;
+                st_issue = (st_issue + 1 == C_::STAGES) ? 0 : st_issue + 1;
             };
-            issue(kbeg, 0);
-            if (DEPTH > 1 && nfull > 1) issue(kbeg + BK, 1);
+            issue();
+            if (DEPTH > 1 && nfull > 1) issue();
+            int st_comp = 0;
             for (int kt = 0; kt < nfull; ++kt) {
                 // my own copies of tile kt have landed (with three stages tile kt+1 may stay in flight) ...
                 if (DEPTH > 1 && kt + 1 < nfull) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C_::GLDS_PER_WAVE) : "memory");
@@ -368,8 +401,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                 // ... and after the barrier everybody's have; everybody has also finished reading the stage refilled next
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (kt + DEPTH < nfull) issue(kbeg + (kt + DEPTH) * BK, (kt + DEPTH) % C_::STAGES);
-                compute(kt % C_::STAGES);
+                if (kt + DEPTH < nfull) issue();
+                compute(st_comp);
+                st_comp = (st_comp + 1 == C_::STAGES) ? 0 : st_comp + 1;
             }
             // a partial last K tile goes through the guarded register path into the stage nobody reads any more
             if (nfull * BK < kend - kbeg) {
@@ -408,6 +442,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
 
     #pragma unroll
     for (int j = 0; j < TN; ++j) {
+        if (j >= jv) continue;                      // nothing accumulated there (tail_reduce never reads those columns)
         #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int gj = scol0 + wcol + 16 * j + q + 4 * g;
@@ -499,9 +534,9 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(const double* __restri
 }
 
 template <bool CPLX, bool OPA_C, int TAG>
-static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha, const double* A, long lda,
-                       const double* B, long ldb, const double* beta, double* C, long ldc,
-                       double* ws, size_t ws_bytes, int num_cu)
+static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* alpha, const double* A, long lda,
+                            const double* B, long ldb, const double* beta, double* C, long ldc,
+                            double* ws, size_t ws_bytes, int num_cu)
 {
     using C_ = Cfg<CPLX, OPA_C>;
     if (m <= 0 || n <= 0) return 0;
@@ -530,20 +565,48 @@ static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha,
     int kchunk = ((nkt + sk - 1) / sk) * C_::BK;
     a.full_tiles = (int)full; a.tail_sk = sk; a.tail_kchunk = kchunk; a.slabs = ws;
     // global_load_lds moves 16 bytes per lane: complex elements always qualify, real ones need even leading dimensions
-    a.glds_ok = (((uintptr_t)A | (uintptr_t)B) % 16 == 0) && (CPLX || ((lda % 2 == 0) && (ldb % 2 == 0)));
+    a.glds_ok = (((uintptr_t)A | (uintptr_t)B) % 16 == 0) && (CPLX || ((lda % 2 == 0) && (ldb % 2 == 0))) &&
+                (double)std::max(lda, ldb) * C_::BM * C_::EPT * 8 < 4.0e9;      // per-lane byte offsets are 32-bit
     const unsigned grid = (unsigned)(full + tail * sk);
     const size_t lds_bytes = (size_t)C_::STAGES * C_::STAGE_UNITS * sizeof(d2_t);
+    // ragged: some 16-column group of the last column tile lies entirely past n
+    const bool ragged = (a.gn * C_::BN - n) >= 16;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG>), dim3(grid), dim3(256), lds_bytes, st, a);
+    if (ragged) hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG, true>), dim3(grid), dim3(256), lds_bytes, st, a);
+    else        hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG, false>), dim3(grid), dim3(256), lds_bytes, st, a);
     if (tail > 0) {
         hipLaunchKernelGGL((tail_reduce_kernel<CPLX, C_::BM, C_::BN>), dim3((unsigned)tail), dim3(256), 0, st, ws,
                            (int)full, sk, a.gn, m, n, C, ldc, a.alpha_re, a.alpha_im, a.beta_re, a.beta_im);
     }
     return (int)hipGetLastError();
+}
+
+// A ragged last column tile (n % BN != 0) is cheap only next to its own kind: the matrix-core arbiter favours the older
+// wave, so a partial-tile workgroup sharing a CU with a whole-tile one advances at the whole tile's pace (measured: no
+// gain from skipped MFMAs when mixed).  The ragged column therefore gets its own launch, K-split over the whole chip,
+// where every workgroup skips the same 16-column groups.
+template <bool CPLX, bool OPA_C, int TAG>
+static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha, const double* A, long lda,
+                       const double* B, long ldb, const double* beta, double* C, long ldc,
+                       double* ws, size_t ws_bytes, int num_cu)
+{
+    using C_ = Cfg<CPLX, OPA_C>;
+    constexpr int EPT = C_::EPT;
+    const int rem = n % C_::BN;
+    const bool balanced = (C_::WAVES_N == 1);          // all waves span the tile width: skipped groups cost nobody
+    if (balanced && n > C_::BN && rem != 0 && rem <= C_::BN - 16 && ws != nullptr) {
+        const int n1 = n - rem;
+        int rc = launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n1, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu);
+        if (rc) return rc;
+        return launch_gemm_part<CPLX, OPA_C, TAG>(st, m, rem, k, alpha, A, lda, B + (long)n1 * ldb * EPT, ldb, beta,
+                                                  C + (long)n1 * ldc * EPT, ldc, ws, ws_bytes, num_cu);
+    }
+    return launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu);
 }
 
 int gemm_f64(hipStream_t st, bool cplx, char opA, int m, int n, int k, const double* alpha, const double* A, long lda,

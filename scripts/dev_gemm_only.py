@@ -1,7 +1,8 @@
 """Single-kernel driver for profiling: filter-shaped HEMM at cfg2 size, random dense operands."""
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from chase_amd.capi import Context, lib, check
 cplx = (sys.argv[1] == "z") if len(sys.argv) > 1 else True
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
