@@ -133,6 +133,8 @@ def run_single(args):
                      "achieved": gflops / 1e3, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": gflops / 1e3 / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                      "launches": calls, "avg_launch_ms": filt_s * 1e3 / max(calls, 1),
+                     "launch_unit": "one HEMM call = whole-tile kernel (+ ragged-column kernel when the width is not a "
+                                    "multiple of the tile width) + tail reduce; rocprofv3: sum over the TAG=1 kernels",
                      "flop_per_launch_avg": flops / max(calls, 1)},
     }
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
