@@ -178,6 +178,18 @@ class Context:
                                         float(perturb), seed), "gen_clement")
         return dH
 
+    def load_matrix(self, path, N, cplx):
+        """Whole N x N matrix from a raw column-major binary file (the reference's input format) into HBM."""
+        dH = self.empty((N, N), np.complex128 if cplx else np.float64)
+        check(lib.chase_hip_load_matrix_shard(self.h, str(path).encode(), int(cplx), N, N, N, N, 1, 0, N, 1, 0, dH.ptr, N),
+              "load_matrix_shard")
+        return dH
+
+    def save_matrix(self, path, dA):
+        cplx = dA.dtype == np.complex128
+        check(lib.chase_hip_save_matrix(self.h, str(path).encode(), int(cplx), dA.shape[0],
+                                        dA.shape[1] if len(dA.shape) > 1 else 1, dA.ptr, dA.shape[0]), "save_matrix")
+
     def gen_bse(self, N, cplx=True, dmin=1.0, dmax=11.0, offdiag=1e-3, seed=7):
         """Whole N x N synthetic Bethe-Salpeter matrix generated in HBM (see chase_hip_gen_bse)."""
         dH = self.empty((N, N), np.complex128 if cplx else np.float64)
@@ -207,6 +219,9 @@ _sig("chase_hip_gen_clement", c_int, c_void_p, c_int, c_void_p, c_long, c_int, c
      c_long, c_int, c_int, c_int, c_long, c_double, c_double, C.c_ulonglong)
 _sig("chase_hip_gen_bse", c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_int, c_long, c_int, c_int, c_int, c_int, c_int,
      c_int, c_double, c_double, c_double, C.c_ulonglong)
+_sig("chase_hip_load_matrix_shard", c_int, c_void_p, C.c_char_p, c_int, c_long, c_int, c_int, c_int, c_int, c_int, c_int,
+     c_int, c_int, c_void_p, c_long)
+_sig("chase_hip_save_matrix", c_int, c_void_p, C.c_char_p, c_int, c_int, c_int, c_void_p, c_long)
 _sig("chase_hip_shift_diag", c_int, c_void_p, c_int, c_int, c_void_p, c_long, c_double)
 _sig("chase_hip_shift_list", c_int, c_void_p, c_int, c_void_p, c_long, c_void_p, c_void_p, c_int, c_double)
 _sig("chase_hip_lacpy", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long)

@@ -32,7 +32,10 @@ static int grid_common(chase_hip_grid* g, chase_hip_ctx* ctx, int nprow, int npc
     g->myrow = rank % nprow;                       // column-major grid ordering (grid/mpiGrid2D.hpp:402-432)
     g->mycol = rank / nprow;
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipStreamCreateWithFlags(&g->comm_stream, hipStreamNonBlocking));
+    // the collectives' few workgroups must not queue behind a chip-filling GEMM launch: highest stream priority
+    int prio_lo = 0, prio_hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIPCHK(hipStreamCreateWithPriority(&g->comm_stream, hipStreamNonBlocking, prio_hi));
     HIPCHK(hipEventCreateWithFlags(&g->ev_compute, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&g->ev_comm, hipEventDisableTiming));
     HIPCHK(hipMalloc((void**)&g->scal_dev, 64));

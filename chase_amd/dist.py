@@ -270,3 +270,12 @@ def gen_bse_local(ctx, N, cplx, rl, cl, myrow, mycol, dmin=1.0, dmax=11.0, offdi
     check(lib.chase_hip_gen_bse(ctx.h, int(cplx), dH.ptr, m, m, n, N, rl.nb, rl.p, myrow, cl.nb, cl.p, mycol,
                                 float(dmin), float(dmax), float(offdiag), seed), "gen_bse")
     return dH
+
+
+def load_matrix_local(ctx, path, N, cplx, rl, cl, myrow, mycol):
+    """This rank's shard of a raw column-major binary matrix file, read straight into HBM (chase_hip_load_matrix_shard)."""
+    m, n = rl.count(myrow), cl.count(mycol)
+    dH = ctx.empty((m, n), np.complex128 if cplx else np.float64)
+    check(lib.chase_hip_load_matrix_shard(ctx.h, str(path).encode(), int(cplx), N, m, n, rl.nb, rl.p, myrow, cl.nb, cl.p,
+                                          mycol, dH.ptr, m), "load_matrix_shard")
+    return dH

@@ -29,6 +29,7 @@ extern "C" {
 #define CHASE_HIP_ENOTCONV (-1004) /* host eigensolver / iteration failed to converge */
 #define CHASE_HIP_ECOMM (-1005)    /* RCCL / transport error */
 #define CHASE_HIP_ELAPACK (-1006)  /* host LAPACK provider missing */
+#define CHASE_HIP_EIO (-1007)      /* matrix file missing, too small or unreadable */
 
 typedef struct chase_hip_ctx chase_hip_ctx;
 
@@ -94,6 +95,15 @@ int chase_hip_gen_clement(chase_hip_ctx* ctx, int cplx, void* H, long ldh, int m
  * examples/5_bse_benchmark/5_bse_benchmark.cpp (BASELINE config 5) */
 int chase_hip_gen_bse(chase_hip_ctx* ctx, int cplx, void* H, long ldh, int mloc, int nloc, long N, int mb, int pr, int pi,
                       int nb, int pc, int pj, double dmin, double dmax, double offdiag, unsigned long long seed);
+/* Raw column-major binary matrix files (N x N elements of T, no header; the reference's input format):
+ * chase_hip_load_matrix_shard reads this rank's (mb x nb block-cyclic; block layout: mb = nb = block length) shard of
+ * the file straight into a device block — replaces Matrix::readFromBinaryFile (linalg/matrix/matrix.hpp:313-360) and the
+ * BlockBlock / BlockCyclic readFromBinaryFile views (linalg/distMatrix/distMatrix.hpp:2425-2520, 3210-3330).  A file
+ * smaller than N*N elements is an error, a larger one is accepted, like the reference.
+ * chase_hip_save_matrix writes a device matrix (m x n, ld) as such a file (Matrix::saveToBinaryFile). */
+int chase_hip_load_matrix_shard(chase_hip_ctx* ctx, const char* path, int cplx, long N, int mloc, int nloc, int mb,
+                                int pr, int pi, int nb, int pc, int pj, void* dev, long ldd);
+int chase_hip_save_matrix(chase_hip_ctx* ctx, const char* path, int cplx, int m, int n, const void* dev, long ldd);
 
 /* ---- host LAPACK provider (HEEVD / STEMR stay on the host per the north star) --------------------------------- */
 int chase_hip_set_lapack_lib(const char* path);   /* optional explicit LP64 LAPACK shared library */

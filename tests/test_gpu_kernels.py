@@ -254,3 +254,38 @@ def test_heevd_gpu_small_and_degenerate(ctx, cplx, n):
     assert np.max(np.abs(w - sla.eigvalsh(A))) <= 200 * EPS * np.abs(w).max()
     assert np.linalg.norm(A @ Z - Z * w[None, :]) <= 1e-12 * max(1.0, np.linalg.norm(A))
     assert O.orthogonality(Z) <= 100 * EPS
+
+
+# ---- matrix files (the reference's raw column-major input format) -------------------------------------------------------
+@pytest.mark.parametrize("cplx", [False, True])
+def test_matrix_file_roundtrip_and_shards(ctx, tmp_path, cplx):
+    """save -> load round trip; block and block-cyclic shards read from the file equal the slices of the matrix;
+    the reference's own fixture file loads bit-exactly; a short file is an error (matrix.hpp:313-360)."""
+    from chase_amd import dist as cd
+    from chase_amd.capi import lib
+    rng = np.random.default_rng(5)
+    N = 75
+    A = rng.standard_normal((N, N)) + (1j * rng.standard_normal((N, N)) if cplx else 0)
+    A = np.asfortranarray(A.astype(np.complex128 if cplx else np.float64))
+    path = tmp_path / "A.bin"
+    ctx.save_matrix(path, ctx.array(A))
+    assert np.array_equal(np.fromfile(path, dtype=A.dtype).reshape(N, N, order="F"), A)
+    assert np.array_equal(ctx.load_matrix(path, N, cplx).download(), A)
+    for (mb, pr, pc) in [(0, 2, 2), (0, 3, 2), (8, 2, 3), (16, 4, 2)]:
+        rl, cl = cd.Layout(N, mb, pr), cd.Layout(N, mb, pc)
+        for i in range(pr):
+            for j in range(pc):
+                blk = cd.load_matrix_local(ctx, path, N, cplx, rl, cl, i, j).download()
+                assert np.array_equal(blk, A[np.ix_(rl.globals_of(i), cl.globals_of(j))])
+    # a larger file is accepted (leading N x N of the byte stream), a smaller one is refused
+    assert np.array_equal(ctx.load_matrix(path, N - 5, cplx).download(),
+                          np.fromfile(path, dtype=A.dtype)[: (N - 5) ** 2].reshape(N - 5, N - 5, order="F"))
+    with pytest.raises(Exception):
+        ctx.load_matrix(path, N + 1, cplx)
+    with pytest.raises(Exception):
+        ctx.load_matrix(tmp_path / "missing.bin", N, cplx)
+    if cplx:   # the reference's own BSE fixture file (tests/linalg/internal/BSE_matrices), as its tests read it
+        import os
+        from conftest import REF_FIX
+        ref = read_ref_matrix("cdouble_random_BSE.bin", 200, 200, True)
+        assert np.array_equal(ctx.load_matrix(os.path.join(REF_FIX, "cdouble_random_BSE.bin"), 200, True).download(), ref)
