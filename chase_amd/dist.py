@@ -228,6 +228,11 @@ class DistSolver:
     def Swap(self, i, j): check(lib.chase_hip_op_swap(self.h, i, j), "Swap")
     def Lock(self, n): check(lib.chase_hip_op_lock(self.h, n), "Lock")
 
+    def checkSymmetryEasy(self):
+        f = c_int()
+        check(lib.chase_hip_op_check_symmetry(self.h, C.byref(f)), "checkSymmetryEasy")
+        return bool(f.value)
+
     def Lanczos(self, M, numvec):
         ub = c_double()
         theta, tau, ritzV = np.zeros(M * numvec), np.zeros(M * numvec), np.zeros(M * M)

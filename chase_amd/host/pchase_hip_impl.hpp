@@ -102,10 +102,45 @@ public:
     ConfigT& GetConfig() override { return config_; }
     int get_nprocs() override { return nprow_ * npcol_; }
     int get_rank() override { return myrow_ + mycol_ * nprow_; }
-    bool isSym() override { return true; }
+    bool isSym() override { return is_sym_; }
     bool isPseudoHerm() override { return false; }
     bool checkPseudoHermicityEasy() override { return false; }
-    bool checkSymmetryEasy() override { return true; }   // TODO(next): distributed randomized check
+    // randomized test H^H v == H v on the grid (linalg/internal/mpi/symOrHerm.hpp:46-96): v ~ N(0,1) column-type seeded
+    // 1337 + grid row, u = H_loc^H v (all-reduce over the column group), uT = H_loc v_rowtype (all-reduce over the row
+    // group), compared elementwise with the reference's absolute 1e-10 after bringing u back to the column-type layout
+    bool checkSymmetryEasy() override
+    {
+        flush_swaps(); sync_comm();
+        void* blk = nullptr;
+        const std::size_t elems = 3 * m_ + 2 * n_;
+        int rc = chase_hip_malloc(ctx_, &blk, elems * sizeof(T));
+        if (rc) throw HipStatusError(rc, "checkSymmetryEasy workspace");
+        int bad = 0;
+        try {
+            T* v = (T*)blk; T* uT = v + m_; T* ucol = uT + m_; T* v2 = ucol + m_; T* u = v2 + n_;
+            std::vector<T> h(m_), hu(m_), hut(m_);
+            std::mt19937 gen(1337.0 + myrow_);
+            std::normal_distribution<> d;
+            for (auto& x : h) x = rnd(d, gen);
+            hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)m_, 1, h.data(), (long)m_, v, (long)m_), "upload v");
+            redistribute_c2r(v, v2, 1);
+            const bool pseudo = pseudo_;
+            pseudo_ = false;                                   // the plain products, whatever the matrix type
+            hemm_ptr(true, v, u, 0, 1, T(1), T(0), false);
+            hemm_ptr(false, v2, uT, 0, 1, T(1), T(0), false);
+            pseudo_ = pseudo;
+            redistribute_r2c(u, ucol, 1);
+            hip_ok(chase_hip_download_matrix(ctx_, CP, (int)m_, 1, ucol, (long)m_, hu.data(), (long)m_), "download");
+            hip_ok(chase_hip_download_matrix(ctx_, CP, (int)m_, 1, uT, (long)m_, hut.data(), (long)m_), "download");
+            for (std::size_t i = 0; i < m_; ++i)
+                if (!(std::abs(hu[i] - hut[i]) <= 1e-10)) { bad = 1; break; }
+        } catch (...) { chase_hip_free(ctx_, blk); throw; }
+        chase_hip_free(ctx_, blk);
+        coll(chase_hip_grid_agree_max(grid_, &bad));
+        is_sym_ = (bad == 0);
+        return is_sym_;
+    }
+    // the reference needs ScaLAPACK (p?tran) for this on a grid and throws without it (mpi/symOrHerm.hpp:128-320)
     void symOrHermMatrix(char) override { throw std::logic_error("pChaseHip: symOrHermMatrix not available on shards"); }
     void Sort(R*, R*, R*) override {}
     void ApplyKconjugate(std::size_t) override {}
@@ -618,7 +653,7 @@ protected:
     Dim Rr_, Cc_;
     std::size_t m_ = 0, n_ = 0;
     std::size_t locked_ = 0, lanczosIter_ = 0, numLanczos_ = 0;
-    bool next_bAc_ = true, device_rng_ = false, pipeline_ = true, pseudo_ = false;
+    bool next_bAc_ = true, device_rng_ = false, pipeline_ = true, pseudo_ = false, is_sym_ = true;
     T *dV1_ = nullptr, *dV2_ = nullptr, *dVt_ = nullptr, *dW1_ = nullptr, *dW2_ = nullptr, *dA_ = nullptr;
     T *dPack_ = nullptr, *dStage_ = nullptr;
     std::size_t pack_elems_ = 0;

@@ -171,6 +171,23 @@ def scenario_solve(ctx, grid, rank, world, N, nev, nex, cplx, mb, deg):
     s.close()
 
 
+def scenario_symcheck(ctx, grid, rank, world, cplx, mb):
+    """Distributed randomized Hermiticity test (mpi/symOrHerm.hpp:46-96): true on a Hermitian matrix, false on every
+    rank once a single off-diagonal entry is changed anywhere."""
+    N = 150
+    H = O.clement(N, cplx, perturb=1e-3)
+    rl, cl = cd.Layout(N, mb, grid.nprow), cd.Layout(N, mb, grid.npcol)
+    for (Hm, expect) in [(H, True), (None, False)]:
+        if Hm is None:
+            Hm = H.copy()
+            Hm[N - 3, 7] += 1e-6                       # breaks Hermiticity in one entry of one shard
+        dH = ctx.array(cd.local_block_of(Hm, rl, cl, grid.myrow, grid.mycol))
+        s = cd.DistSolver(ctx, grid, dH, N, 8, 4, cplx, mb, mb)
+        got = s.checkSymmetryEasy()
+        assert got == expect, (got, expect)
+        s.close()
+
+
 def bse_fixture():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import conftest
@@ -287,6 +304,8 @@ def main():
         elif scen == "solve":
             N, nev, nex = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
             scenario_solve(ctx, grid, rank, world, N, nev, nex, sys.argv[6] == "z", int(sys.argv[7]), int(sys.argv[8]))
+        elif scen == "symcheck":
+            scenario_symcheck(ctx, grid, rank, world, sys.argv[3] == "z", int(sys.argv[4]))
         elif scen == "pseudo_ops":
             scenario_pseudo_ops(ctx, grid, rank, world, int(sys.argv[3]))
         elif scen == "pseudo_solve":

@@ -65,3 +65,8 @@ def test_pseudo_solve_bse_fixture(nranks, mb):
 
 def test_pseudo_solve_rccl_single_rank():
     run_ranks(1, "rccl", "pseudo_solve", 0)
+
+
+@pytest.mark.parametrize("nranks,typ,mb", [(4, "z", 0), (6, "d", 16), (1, "z", 0)])
+def test_distributed_symmetry_check(nranks, typ, mb):
+    run_ranks(nranks, "host", "symcheck", typ, mb)
