@@ -158,7 +158,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=None)
-    ap.add_argument("--n", type=int, default=0, help="override N (development only)")
+    ap.add_argument("--n", "--size", dest="n", type=int, default=0, help="override N (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
     ap.add_argument("--block-cyclic", type=int, default=-1,

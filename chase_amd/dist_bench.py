@@ -29,7 +29,8 @@ def run_distributed(args):
     ndev = torch.cuda.device_count()
     ctx = Context(local_rank % max(ndev, 1))
     pg = cd.make_process_groups(nprow, npcol)
-    grid = cd.Grid(ctx, nprow, npcol, rank, transport=os.environ.get("CHASE_HIP_TRANSPORT", "rccl"), pg=pg)
+    transport = os.environ.get("CHASE_HIP_TRANSPORT", "rccl")
+    grid = cd.Grid(ctx, nprow, npcol, rank, transport=transport, pg=pg)
     mb = nb = args.block_cyclic if args.block_cyclic >= 0 else B.DEFAULT_BLOCK_CYCLIC.get(workload, 0)
     rl, cl = cd.Layout(N, mb, nprow), cd.Layout(N, nb, npcol)
     pseudo = workload in B.PSEUDO_WORKLOADS
@@ -81,7 +82,8 @@ def run_distributed(args):
                                    + ("synthetic Bethe-Salpeter pseudo-Hermitian (Solve_pseudo, H^2 filter)" if pseudo
                                       else "perturbed Clement-type Hermitian (x100/N)") + f" N={N} "
                                    f"{'complex' if cplx else 'real'} fp64, nev={nev} nex={nex}, tol 1e-10, deg 20 opt, "
-                                   f"{nprow}x{npcol} {'block-cyclic nb=%d' % nb if nb else 'block'} grid, RCCL",
+                                   f"{nprow}x{npcol} {'block-cyclic nb=%d' % nb if nb else 'block'} grid, "
+                                   + ("RCCL" if transport == "rccl" else "host-callback (gloo) transport"),
                        "N": N, "nev": nev, "nex": nex, "grid": f"{nprow}x{npcol}"},
             "eigenpairs_per_sec": nev / (wall / args.steps),
             "pct_fp64_mfma_peak": 100.0 * gflops / 1e3 / world / B.FP64_MFMA_PEAK_TFLOPS,
