@@ -215,7 +215,7 @@ int chase_hip_gemm_z(chase_hip_ctx* c, char opA, int m, int n, int k, const doub
 int chase_hip_mfma_f64_peak(chase_hip_ctx* c, double* tflops)
 {
     if (!c || !tflops) return set_error(CHASE_HIP_EINVAL, "mfma_peak: NULL argument");
-    const int blocks = c->num_cu * 2, iters = 4096;
+    const int blocks = c->num_cu * 2, iters = 16384;           // ~7 ms at peak: long enough for the clock to settle
     double* out = nullptr;
     HIPCHK(hipMalloc((void**)&out, (size_t)blocks * 256 * sizeof(double)));
     mfma_f64_peak(c->stream, out, blocks, 64); // warm-up
@@ -231,8 +231,8 @@ int chase_hip_mfma_f64_peak(chase_hip_ctx* c, double* tflops)
         if (ms < best) best = ms;
     }
     HIPCHK(hipFree(out));
-    // per wave per iteration: 8 MFMAs x (16*16*4*2) flops
-    const double flops = (double)blocks * 4 /*waves*/ * iters * 8.0 * 2048.0;
+    // per wave per iteration: 16 MFMAs x (16*16*4*2) flops
+    const double flops = (double)blocks * 4 /*waves*/ * iters * 16.0 * 2048.0;
     *tflops = flops / (best * 1e-3) / 1e12;
     return 0;
 }

@@ -241,103 +241,101 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
     // costs what its valid columns cost and the freed matrix-core time goes to the co-resident workgroup
     const int jv = RAGGED ? __builtin_amdgcn_readfirstlane(min(TN, max(0, (p.n - col0 - wcol + 15) >> 4))) : TN;
 
-    auto compute = [&](int stage) __attribute__((always_inline)) {
-        constexpr bool FULL = !RAGGED;                        // FULL: every 16-column group is live (no per-group branches)
+    // Fragments of one 4-unit K chunk: b[j] = 16-byte unit of column tile j, a[i][.] = the two doubles of row tile i's unit
+    // (complex: re, im of one element; real: the chunk's two k values s = 0, 1).
+    struct Frag { d2_t b[TN]; double a[TM][2]; };
+
+    auto read_chunk = [&](int stage, int ch, Frag& f) __attribute__((always_inline)) {
         const d2_t* sA = lds + stage * C_::STAGE_UNITS;
         const d2_t* sB = sA + C_::A_UNITS;
-        if constexpr (CPLX) {
-            // fragments of BOTH 4-deep chunks are fetched up front so that the second chunk's LDS latency is covered by
-            // the first chunk's 32 MFMAs (the compiler otherwise issues those reads only after the last MFMA)
-            d2_t fb[2][TN], fa[2][TM];
+        const int ku = 4 * ch + q;
+        #pragma unroll
+        for (int j = 0; j < TN; ++j) f.b[j] = sB[kidx(wcol + 16 * j + c16, ku)];
+        if constexpr (CPLX || OPA_C) {
             #pragma unroll
-            for (int ch = 0; ch < 2; ++ch) {
-                const int ku = 4 * ch + q;
-                #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int r = wcol + 16 * j + c16;
-                    fb[ch][j] = sB[kidx(r, ku)];
-                }
-                #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int r = wrow + 16 * i + c16;
-                    if constexpr (OPA_C) fa[ch][i] = sA[kidx(r, ku)];
-                    else                 fa[ch][i] = sA[ku * UM + r];
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            #pragma unroll
-            for (int ch = 0; ch < 2; ++ch) {
-                // op=N: (ar + i ai)(br + i bi): re = br ar - bi ai, im = bi ar + br ai
-                // op=C: (ar - i ai)(br + i bi): re = br ar + bi ai, im = bi ar - br ai      -> one negated B value per tile
-                double nb[TN];
-                #pragma unroll
-                for (int j = 0; j < TN; ++j) nb[j] = OPA_C ? -fb[ch][j].x : -fb[ch][j].y;
-                #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    if (FULL || j < jv)
-                    #pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ch][j].x, fa[ch][i].x, acc[0][j][i], 0, 0, 0);
-                        acc[1][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ch][j].y, fa[ch][i].x, acc[1][j][i], 0, 0, 0);
-                    }
-                #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    if (FULL || j < jv)
-                    #pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(OPA_C ? fb[ch][j].y : nb[j], fa[ch][i].y, acc[0][j][i], 0, 0, 0);
-                        acc[1][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(OPA_C ? nb[j] : fb[ch][j].x, fa[ch][i].y, acc[1][j][i], 0, 0, 0);
-                    }
+            for (int i = 0; i < TM; ++i) {
+                const int r = wrow + 16 * i + c16;
+                d2_t v;
+                if constexpr (OPA_C) v = sA[kidx(r, ku)];
+                else                 v = sA[ku * UM + r];
+                f.a[i][0] = v.x; f.a[i][1] = v.y;
             }
         } else {
+            // real, M-contiguous A: unit = rows (2u, 2u+1) at one k; MFMA step s uses k = 8*ch + 2*q + s
             #pragma unroll
-            for (int ch = 0; ch < 2; ++ch) {            // two 4-unit chunks along K per stage
-                const int ku = 4 * ch + q;
-                d2_t fb[TN];
+            for (int pr = 0; pr < TM / 2; ++pr)
                 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int r = wcol + 16 * j + c16;
-                    fb[j] = sB[kidx(r, ku)];
+                for (int s = 0; s < 2; ++s) {
+                    const int kk = 8 * ch + 2 * q + s;
+                    const d2_t v = sA[kk * UM + (wrow / 2) + 16 * pr + c16];
+                    f.a[2 * pr][s] = v.x;
+                    f.a[2 * pr + 1][s] = v.y;
                 }
-                // real: per chunk two MFMA k-steps s = 0,1 using k = 8*ch + 2*q + s
-                double fa[TM][2];                   // [tile][s]
-                if constexpr (OPA_C) {
-                    #pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        const int r = wrow + 16 * i + c16;
-                        const d2_t v = sA[kidx(r, ku)];
-                        fa[i][0] = v.x; fa[i][1] = v.y;
-                    }
-                } else {
-                    #pragma unroll
-                    for (int pr = 0; pr < TM / 2; ++pr)
-                        #pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            const int kk = 8 * ch + 2 * q + s;
-                            const d2_t v = sA[kk * UM + (wrow / 2) + 16 * pr + c16];   // rows (2u, 2u+1)
-                            fa[2 * pr][s] = v.x;
-                            fa[2 * pr + 1][s] = v.y;
-                        }
-                }
+        }
+    };
+
+    auto mfma_chunk = [&](const Frag& f) __attribute__((always_inline)) {
+        constexpr bool FULL = !RAGGED;                        // FULL: every 16-column group is live (no per-group branches)
+        if constexpr (CPLX) {
+            // op=N: (ar + i ai)(br + i bi): re = br ar - bi ai, im = bi ar + br ai
+            // op=C: (ar - i ai)(br + i bi): re = br ar + bi ai, im = bi ar - br ai      -> one negated B value per tile
+            double nb[TN];
+            #pragma unroll
+            for (int j = 0; j < TN; ++j) nb[j] = OPA_C ? -f.b[j].x : -f.b[j].y;
+            #pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (FULL || j < jv)
                 #pragma unroll
-                for (int s = 0; s < 2; ++s)
+                for (int i = 0; i < TM; ++i) {
+                    acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.b[j].x, f.a[i][0], acc[0][j][i], 0, 0, 0);
+                    acc[1][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.b[j].y, f.a[i][0], acc[1][j][i], 0, 0, 0);
+                }
+            #pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (FULL || j < jv)
+                #pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(OPA_C ? f.b[j].y : nb[j], f.a[i][1], acc[0][j][i], 0, 0, 0);
+                    acc[1][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(OPA_C ? nb[j] : f.b[j].x, f.a[i][1], acc[1][j][i], 0, 0, 0);
+                }
+        } else {
+            #pragma unroll
+            for (int s = 0; s < 2; ++s)
+                #pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (FULL || j < jv)
                     #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        if (FULL || j < jv)
-                        #pragma unroll
-                        for (int i = 0; i < TM; ++i)
-                            acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(
-                                s == 0 ? fb[j].x : fb[j].y, fa[i][s], acc[0][j][i], 0, 0, 0);
+                    for (int i = 0; i < TM; ++i)
+                        acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                            s == 0 ? f.b[j].x : f.b[j].y, f.a[i][s], acc[0][j][i], 0, 0, 0);
+        }
+    };
+
+    // whole K step from one LDS stage (register-staged fallback path)
+    auto compute = [&](int stage) __attribute__((always_inline)) {
+        if constexpr (CPLX) {
+            Frag f0, f1;
+            read_chunk(stage, 0, f0);
+            read_chunk(stage, 1, f1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_chunk(f0);
+            mfma_chunk(f1);
+        } else {                                             // 40 fragment registers per chunk: one chunk at a time
+            #pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                Frag f;
+                read_chunk(stage, ch, f);
+                mfma_chunk(f);
             }
         }
     };
+
     // ---- main loop ----------------------------------------------------------------------------------------------
     bool done = false;
     {
         // Interior workgroups: asynchronous global -> LDS copies (global_load_lds_dwordx4, no staging registers, no
         // ds_write pass); complex: three LDS stages, tile kt+2 in flight while tile kt is multiplied; real: two stages,
         // tile kt+1 in flight.  One raw s_barrier and one COUNTED vmcnt per K step.
-        constexpr int DEPTH = C_::STAGES - 1;
         const int nfull = (kend - kbeg) / BK;
         // column-edge workgroups qualify too: B rows past n are clamped to the last valid column (their products are
         // never stored), only a ragged M edge needs the guarded register path
@@ -391,19 +389,61 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                 sb += stepB;
                 st_issue = (st_issue + 1 == C_::STAGES) ? 0 : st_issue + 1;
             };
-            issue();
-            if (DEPTH > 1 && nfull > 1) issue();
-            int st_comp = 0;
-            for (int kt = 0; kt < nfull; ++kt) {
-                // my own copies of tile kt have landed (with three stages tile kt+1 may stay in flight) ...
-                if (DEPTH > 1 && kt + 1 < nfull) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C_::GLDS_PER_WAVE) : "memory");
-                else                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                // ... and after the barrier everybody's have; everybody has also finished reading the stage refilled next
+            if constexpr (CPLX) {
+                // Software pipeline: all STAGES tiles are requested up front; each K step multiplies chunk 0 from registers
+                // while chunk 1's fragments stream in from LDS, and the barrier that publishes tile kt+1 sits BETWEEN the two
+                // MFMA clusters, so chunk 0 of tile kt+1 is fetched under chunk 1's MFMAs and the stage of tile kt is refilled
+                // (tile kt+STAGES) as soon as its last fragment has been read: no MFMA ever waits for an LDS read.
+                constexpr int G = C_::GLDS_PER_WAVE;
+                const int npre = min(nfull, C_::STAGES);
+                for (int t = 0; t < npre; ++t) issue();
+                if (npre == 3)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+                else if (npre == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+                else                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (kt + DEPTH < nfull) issue();
-                compute(st_comp);
-                st_comp = (st_comp + 1 == C_::STAGES) ? 0 : st_comp + 1;
+                Frag fA, fB;
+                read_chunk(0, 0, fA);
+                int st = 0;
+                for (int kt = 0; kt < nfull; ++kt) {
+                    const int stn = (st + 1 == C_::STAGES) ? 0 : st + 1;
+                    read_chunk(st, 1, fB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_chunk(fA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kt + 1 < nfull) {
+                        // my reads of stage st are complete (it is refilled below) and my copies of tile kt+1 have landed;
+                        // a later tile may stay in flight (three stages)
+                        if (C_::STAGES > 2 && kt + 2 < nfull) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
+                        else                                  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                        read_chunk(stn, 0, fA);
+                        if (kt + C_::STAGES < nfull) issue();                 // tile kt+STAGES into stage st
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_chunk(fB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    st = stn;
+                }
+            } else {
+                // real: 80 fragment registers would not fit next to the 64 accumulators; one barrier per K step, fragments
+                // fetched at the head of each step (two LDS stages, tile kt+1 in flight)
+                constexpr int DEPTH = C_::STAGES - 1;
+                issue();
+                if (DEPTH > 1 && nfull > 1) issue();
+                int st_comp = 0;
+                for (int kt = 0; kt < nfull; ++kt) {
+                    // my own copies of tile kt have landed (with three stages tile kt+1 may stay in flight) ...
+                    if (DEPTH > 1 && kt + 1 < nfull) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C_::GLDS_PER_WAVE) : "memory");
+                    else                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    // ... and after the barrier everybody's have; everybody has also finished reading the stage refilled next
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (kt + DEPTH < nfull) issue();
+                    compute(st_comp);
+                    st_comp = (st_comp + 1 == C_::STAGES) ? 0 : st_comp + 1;
+                }
             }
             // a partial last K tile goes through the guarded register path into the stage nobody reads any more
             if (nfull * BK < kend - kbeg) {
@@ -623,19 +663,20 @@ int gemm_f64(hipStream_t st, bool cplx, char opA, int m, int n, int k, const dou
 }
 
 // ---- register-resident MFMA peak probe ("to be confirmed by a register-resident MFMA micro-benchmark")
-__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int iters)
+__global__ __launch_bounds__(256, 2) void mfma_f64_peak_kernel(double* out, int iters)
 {
-    d4_t acc[8];
+    // 16 independent accumulators per wave (the GEMM's count), two workgroups per CU = two waves per SIMD
+    d4_t acc[16];
     #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = d4_t{0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < 16; ++i) acc[i] = d4_t{0.0, 0.0, 0.0, 0.0};
     double a = 1.0 + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
     for (int it = 0; it < iters; ++it) {
         #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
     }
     double s = 0.0;
     #pragma unroll
-    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
