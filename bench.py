@@ -161,11 +161,13 @@ def main():
     ap.add_argument("--n", "--size", dest="n", type=int, default=0, help="override N (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
+    ap.add_argument("--dist", action="store_true",
+                    help="run the grid Impl (pChaseHip) even on one GPU (1x1 grid; development: panel-pipeline overheads)")
     ap.add_argument("--block-cyclic", type=int, default=-1,
                     help="block size of a block-cyclic H distribution (0 = block layout, -1 = the workload's default)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.workload in PSEUDO_WORKLOADS and world == 1 and args.gpus <= 1:
+    if (args.workload in PSEUDO_WORKLOADS or args.dist) and world == 1 and args.gpus <= 1:
         # the pseudo-Hermitian workload runs the grid Impl on a 1x1 grid (communicator-free) when launched directly
         import socket
         with socket.socket() as so:
