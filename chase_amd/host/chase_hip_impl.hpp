@@ -145,6 +145,7 @@ public:
     // reference: chase_cpu.hpp:296-327 (mt19937(1337), column-major fill) + chase_gpu.hpp:520-537 (copy, H2D)
     void initVecs(bool random) override
     {
+        hv_valid_ = false;
         if (random && device_rng_) {
             // ChASEGPU behaviour: generate on the device (chase_gpu.hpp:520-525), no host staging of N x nevex
             hip_ok(chase_hip_fill_normal(ctx_, CP, (int)N_, (int)nevex_, dV1_, (long)N_, 0, 0, (long)N_, 1337ull), "fill_normal");
@@ -191,13 +192,14 @@ public:
 
     void Shift(T c, bool = false) override
     {
+        hv_valid_ = false;
         hip_ok(chase_hip_shift_diag(ctx_, CP, (int)N_, dH_, (long)ldd_h_, std::real(c)), "shift_diag");
     }
 
     // V2[:, c0:c0+ncols] = alpha * H * V1[:, c0:...] + beta * V2[:, ...], c0 = locked + offset_left; then V1 <-> V2
     void HEMM(std::size_t block, T alpha, T beta, std::size_t offset_left, std::size_t offset_right = 0) override
     {
-        flush_swaps();
+        flush_swaps(); hv_valid_ = false;
         const std::size_t ncols = (offset_right < block) ? block - offset_right : 0;
         if (ncols != 0) {
             const std::size_t c0 = locked_ + offset_left;
@@ -210,7 +212,7 @@ public:
     // ---- QR (chase_cpu.hpp:590-776) --------------------------------------------------------------------------------
     void QR(std::size_t, R cond) override
     {
-        flush_swaps();
+        flush_swaps(); hv_valid_ = false;
         hip_ok(chase_hip_lacpy(ctx_, CP, (int)N_, (int)locked_, dV1_, (long)N_, dV2_, (long)N_), "lacpy");
         int disable = config_.DoCholQR() ? 0 : 1;
         if (const char* s = std::getenv("CHASE_DISABLE_CHOLQR")) disable = std::atoi(s);
@@ -240,6 +242,14 @@ public:
         gemm('C', N_, block, N_, T(1), dH_, ldd_h_, Q, N_, T(0), W, N_);          // W = H^H Q
         gemm('C', block, block, N_, T(1), W, N_, Q, N_, T(0), dA_, block);         // A = W^H Q
         hip_ok(chase_hip_heevd(ctx_, CP, (int)block, dA_, (long)block, ritzv), "heevd");
+        hv_valid_ = false;
+        if (resd_reuse_) {
+            // H (Q A) = (H Q) A: the product the residual step needs costs N*block^2 here instead of N^2*block there
+            // (the reference recomputes H V in Resd, chase_cpu.hpp:805-818; equal up to rounding)
+            if (!dHV_) alloc((void**)&dHV_, N_ * nevex_ * sizeof(T));
+            gemm('N', N_, block, block, T(1), W, N_, dA_, block, T(0), dHV_ + locked_ * N_, N_);
+            hv_valid_ = true; hv_locked_ = locked_; hv_block_ = block;
+        }
         gemm('N', N_, block, block, T(1), Q, N_, dA_, block, T(0), W, N_);         // W = Q A
         std::swap(dV1_, dV2_);
     }
@@ -251,7 +261,9 @@ public:
         const std::size_t sub = nevex_ - locked_;
         T* V = dV1_ + locked_ * N_;
         T* W = dV2_ + locked_ * N_;
-        gemm('N', N_, sub, N_, T(1), dH_, ldd_h_, V, N_, T(0), W, N_);
+        if (hv_valid_ && hv_locked_ == locked_ && hv_block_ == sub) W = dHV_ + locked_ * N_;   // H V left behind by RR
+        else gemm('N', N_, sub, N_, T(1), dH_, ldd_h_, V, N_, T(0), W, N_);
+        hv_valid_ = false;
         hip_ok(chase_hip_resid_norms(ctx_, CP, (int)N_, (int)sub, W, (long)N_, V, (long)N_, ritzv, resd, 0), "resid");
         if (resd != resid_.data() + locked_) std::memcpy(resid_.data() + locked_, resd, sub * sizeof(R));
     }
@@ -279,6 +291,7 @@ public:
     // V1[:, :idx] <- V1[:, :m] * ritzVc[:, :idx]   (chase_cpu.hpp:368-382, incl. its m-column copy-back)
     void LanczosDos(std::size_t idx, std::size_t m, T* ritzVc) override
     {
+        hv_valid_ = false;
         flush_swaps();
         hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)m, (int)idx, ritzVc, (long)m, dA_, (long)m), "upload ritzV");
         gemm('N', N_, idx, m, T(1), dV1_, N_, dA_, m, T(0), dV2_, N_);
@@ -331,6 +344,7 @@ private:
     void flush_swaps()
     {
         if (!perm_dirty_) return;
+        hv_valid_ = false;
         std::vector<int> src, dst;
         for (std::size_t j = 0; j < nevex_; ++j)
             if (perm_[j] != (int)j) { src.push_back(perm_[j]); dst.push_back((int)j); }
@@ -342,7 +356,7 @@ private:
 
     void lanczos_core(std::size_t M, std::size_t nv, bool store, R* upperb, R* theta, R* Tau, R* ritzV)
     {
-        flush_swaps();
+        flush_swaps(); hv_valid_ = false;
         if (!h_resident_) upload_H();
         constexpr int E = CP ? 2 : 1;
         T *v0, *v1, *v2;
@@ -417,8 +431,10 @@ private:
     std::vector<int> perm_;
     bool perm_dirty_ = false;
     std::size_t locked_ = 0, lanczosIter_ = 0, numLanczos_ = 0;
-    T *dH_ = nullptr, *dV1_ = nullptr, *dV2_ = nullptr, *dA_ = nullptr;
+    T *dH_ = nullptr, *dV1_ = nullptr, *dV2_ = nullptr, *dA_ = nullptr, *dHV_ = nullptr;
     std::size_t ldd_h_ = 0;
+    bool hv_valid_ = false, resd_reuse_ = std::getenv("CHASE_HIP_RESD_REUSE") ? std::atoi(std::getenv("CHASE_HIP_RESD_REUSE")) != 0 : true;
+    std::size_t hv_locked_ = 0, hv_block_ = 0;
     std::vector<void*> owned_;
     double filter_ms_ = 0;
     std::size_t hemm_calls_ = 0;

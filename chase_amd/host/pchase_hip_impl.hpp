@@ -168,6 +168,7 @@ public:
     // pchase_cpu.hpp:272-311: every grid row seeds mt19937(1337 + coords[0]) and fills its block in memory order
     void initVecs(bool random) override
     {
+        hv_valid_ = false;
         if (random) {
             if (device_rng_) {
                 hip_ok(chase_hip_fill_normal_bc(ctx_, CP, (int)m_, (int)nc_, dV1_, (long)m_, (long)N_, (int)Rr_.nb,
@@ -188,6 +189,7 @@ public:
     // caller-provided start vectors (approximate-solution mode): local m_loc x nevex block, host memory
     void upload_local_V(const T* host, std::size_t ldv)
     {
+        hv_valid_ = false;
         hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)m_, (int)nc_, host, (long)ldv, dV1_, (long)m_), "upload V");
     }
     void download_local_V(T* host, std::size_t ldv)
@@ -216,6 +218,7 @@ public:
     // mpi/shiftDiagonal.hpp:21-78 / cuda/shiftDiagonal.cu:100-149: shift the locally owned diagonal entries
     void Shift(T c, bool isunshift = false) override
     {
+        hv_valid_ = false;
         if (isunshift) next_bAc_ = true;
         hip_ok(chase_hip_shift_list(ctx_, CP, dH_, (long)ldh_, d_diag_rows_, d_diag_cols_, (int)diag_cnt_, std::real(c)),
                "shift_list");
@@ -223,7 +226,7 @@ public:
 
     void HEMM(std::size_t block, T alpha, T beta, std::size_t offset_left, std::size_t offset_right = 0) override
     {
-        flush_swaps();
+        flush_swaps(); hv_valid_ = false;
         const std::size_t ncols = (offset_right < block) ? block - offset_right : 0;
         if (ncols != 0) {
             hemm_dir(next_bAc_, locked_ + offset_left, ncols, alpha, beta, true);
@@ -235,7 +238,7 @@ public:
     // ---- QR (pchase_cpu.hpp:572-867) -------------------------------------------------------------------------------------
     void QR(std::size_t, R cond) override
     {
-        flush_swaps(); sync_comm();
+        flush_swaps(); sync_comm(); hv_valid_ = false;
         hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)locked_, dV1_, (long)m_, dV2_, (long)m_), "lacpy");
         int disable = config_.DoCholQR() ? 0 : 1;
         if (const char* s = std::getenv("CHASE_DISABLE_CHOLQR")) disable = std::atoi(s);
@@ -268,6 +271,16 @@ public:
         allreduce_packed_upper(dA_, block, CHASE_HIP_ROW);
         hip_ok(chase_hip_heevd(ctx_, CP, (int)block, dA_, (long)block, ritzv), "heevd");
         agree_vector(ritzv, block, dA_, block * block);                      // identical Ritz pairs on every rank
+        hv_valid_ = false;
+        if (resd_reuse_) {
+            // row-type H V and V of the new Ritz vectors without another HEMM / all-reduce / redistribution:
+            // (H^H Q) A and Q A from the row-type blocks this step already holds (the reference recomputes both in
+            // residuals(), mpi/residuals.hpp:61-107; equal up to rounding)
+            if (!dW3_) alloc((void**)&dW3_, n_ * nc_ * sizeof(T));
+            gemm('N', n_, block, block, T(1), dW1_ + c0 * n_, n_, dA_, block, T(0), dW3_ + c0 * n_, n_);
+            gemm('N', n_, block, block, T(1), dW2_ + c0 * n_, n_, dA_, block, T(0), dW1_ + c0 * n_, n_);
+            hv_valid_ = true; hv_locked_ = locked_; hv_block_ = block;
+        }
         gemm('N', m_, block, block, T(1), dV2_ + c0 * m_, m_, dA_, block, T(0), dV1_ + c0 * m_, m_);
         hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)block, dV1_ + c0 * m_, (long)m_, dV2_ + c0 * m_, (long)m_), "lacpy");
     }
@@ -277,9 +290,16 @@ public:
     {
         flush_swaps(); sync_comm();
         const std::size_t c0 = locked_, sub = nevex_ - locked_;
-        hemm_dir(true, c0, sub, T(1), T(0), false);                          // W1 = H^H V1
-        redistribute_c2r(dV2_ + c0 * m_, dW2_ + c0 * n_, sub);               // W2 = V2 (== V1) row-type
-        hip_ok(chase_hip_resid_norms(ctx_, CP, (int)n_, (int)sub, dW1_ + c0 * n_, (long)n_, dW2_ + c0 * n_, (long)n_,
+        const T *HV, *Vr;
+        if (hv_valid_ && hv_locked_ == locked_ && hv_block_ == sub) {        // left behind by RR
+            HV = dW3_ + c0 * n_; Vr = dW1_ + c0 * n_;
+        } else {
+            hemm_dir(true, c0, sub, T(1), T(0), false);                      // W1 = H^H V1
+            redistribute_c2r(dV2_ + c0 * m_, dW2_ + c0 * n_, sub);           // W2 = V2 (== V1) row-type
+            HV = dW1_ + c0 * n_; Vr = dW2_ + c0 * n_;
+        }
+        hv_valid_ = false;
+        hip_ok(chase_hip_resid_norms(ctx_, CP, (int)n_, (int)sub, HV, (long)n_, Vr, (long)n_,
                                      ritzv, resd, 1), "resid_norms");      // local sums of squares
         // all-reduce over the row communicator, then sqrt (mpi/residuals.hpp:99-105)
         double* d = (double*)dPack_;
@@ -313,7 +333,7 @@ public:
     }
     void LanczosDos(std::size_t idx, std::size_t m, T* ritzVc) override
     {
-        flush_swaps(); sync_comm();
+        flush_swaps(); sync_comm(); hv_valid_ = false;
         hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)m, (int)idx, ritzVc, (long)m, dA_, (long)m), "upload ritzV");
         gemm('N', m_, idx, m, T(1), dV1_, m_, dA_, m, T(0), dV2_, m_);
         hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)m, dV2_, (long)m_, dV1_, (long)m_), "lacpy");
@@ -541,6 +561,7 @@ protected:
     void flush_swaps()
     {
         if (!perm_dirty_) return;
+        hv_valid_ = false;
         sync_comm();
         std::vector<int> src, dst;
         for (std::size_t j = 0; j < nc_; ++j)
@@ -557,7 +578,7 @@ protected:
 
     void lanczos_core(std::size_t M, std::size_t nv, bool store, R* upperb, R* theta, R* Tau, R* ritzV)
     {
-        flush_swaps(); sync_comm();
+        flush_swaps(); sync_comm(); hv_valid_ = false;
         T *v0, *v1, *v2, *vw;
         double *d_alpha, *d_beta, *d_tmp;
         void* blk = nullptr;
@@ -654,6 +675,9 @@ protected:
     std::size_t m_ = 0, n_ = 0;
     std::size_t locked_ = 0, lanczosIter_ = 0, numLanczos_ = 0;
     bool next_bAc_ = true, device_rng_ = false, pipeline_ = true, pseudo_ = false, is_sym_ = true;
+    bool hv_valid_ = false, resd_reuse_ = std::getenv("CHASE_HIP_RESD_REUSE") ? std::atoi(std::getenv("CHASE_HIP_RESD_REUSE")) != 0 : true;
+    std::size_t hv_locked_ = 0, hv_block_ = 0;
+    T* dW3_ = nullptr;
     T *dV1_ = nullptr, *dV2_ = nullptr, *dVt_ = nullptr, *dW1_ = nullptr, *dW2_ = nullptr, *dA_ = nullptr;
     T *dPack_ = nullptr, *dStage_ = nullptr;
     std::size_t pack_elems_ = 0;
