@@ -1,5 +1,6 @@
 // capi_core.hip — context, memory plumbing, GEMM and probe entry points of the C ABI (include/chase_hip.h)
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -210,6 +211,12 @@ int chase_hip_gemm_z(chase_hip_ctx* c, char opA, int m, int n, int k, const doub
                      (double*)C, ldc, (double*)c->ws, c->ws_bytes, c->num_cu, c->phase);
     if (e) return hip_fail((hipError_t)e, "gemm_z launch");
     return 0;
+}
+
+int chase_hip_gemm3m_enabled(void)
+{
+    const char* e = getenv("CHASE_HIP_GEMM3M");
+    return (e ? atoi(e) != 0 : 1) ? 1 : 0;
 }
 
 int chase_hip_mfma_f64_peak(chase_hip_ctx* c, double* tflops)

@@ -102,9 +102,15 @@ struct GemmArgs {
 // rocprofv3 --kernel-trace --stats reports the Chebyshev-filter HEMM separately from the QR / RR / residual products.
 // RAGGED: the launch covers a column range whose (single) last column tile needs fewer than TN 16-column groups; only
 // that instantiation carries the per-group branches (the whole-tile one keeps its MFMA clusters branch-free).
-template <bool CPLX, bool OPA_C, int TAG, bool RAGGED>
+// M3 (complex only): three real products per complex product instead of four (the "3M" scheme of zgemm3m),
+//   P1 = sum ar*br, P2 = sum ai*bi, P3 = sum (ar +- ai)(br + bi);  op=N: re = P1 - P2, im = P3 - P1 - P2;
+//   op=C (conj(A)): re = P1 + P2, im = P3 - P1 + P2  with (ar - ai).
+// 25 % fewer MFMAs for the same product; normwise backward stable like the 4-product form (the imaginary part carries the
+// absolute error of the real part), used for the Chebyshev-filter products only.
+template <bool CPLX, bool OPA_C, int TAG, bool RAGGED, bool M3>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
 {
+    static_assert(CPLX || !M3, "3M applies to complex products");
     using C_ = Cfg<CPLX, OPA_C>;
     constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TM = C_::TM, TN = C_::TN;
     constexpr int EPT = C_::EPT, KPU = C_::KPU, RPU = C_::RPU;
@@ -227,9 +233,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
     };
 
     // ---- accumulators -------------------------------------------------------------------------------------------
-    d4_t acc[CPLX ? 2 : 1][TN][TM];
+    constexpr int NACC = CPLX ? (M3 ? 3 : 2) : 1;
+    d4_t acc[NACC][TN][TM];
     #pragma unroll
-    for (int z = 0; z < (CPLX ? 2 : 1); ++z)
+    for (int z = 0; z < NACC; ++z)
         #pragma unroll
         for (int j = 0; j < TN; ++j)
             #pragma unroll
@@ -276,7 +283,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
 
     auto mfma_chunk = [&](const Frag& f) __attribute__((always_inline)) {
         constexpr bool FULL = !RAGGED;                        // FULL: every 16-column group is live (no per-group branches)
-        if constexpr (CPLX) {
+        if constexpr (CPLX && M3) {
+            double sa[TM], sb[TN];
+            #pragma unroll
+            for (int i = 0; i < TM; ++i) sa[i] = OPA_C ? f.a[i][0] - f.a[i][1] : f.a[i][0] + f.a[i][1];
+            #pragma unroll
+            for (int j = 0; j < TN; ++j) sb[j] = f.b[j].x + f.b[j].y;
+            #pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (FULL || j < jv)
+                #pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.b[j].x, f.a[i][0], acc[0][j][i], 0, 0, 0);
+                    acc[1][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.b[j].y, f.a[i][1], acc[1][j][i], 0, 0, 0);
+                    acc[2][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(sb[j], sa[i], acc[2][j][i], 0, 0, 0);
+                }
+        } else if constexpr (CPLX) {
             // op=N: (ar + i ai)(br + i bi): re = br ar - bi ai, im = bi ar + br ai
             // op=C: (ar - i ai)(br + i bi): re = br ar + bi ai, im = bi ar - br ai      -> one negated B value per tile
             double nb[TN];
@@ -313,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
 
     // whole K step from one LDS stage (register-staged fallback path)
     auto compute = [&](int stage) __attribute__((always_inline)) {
-        if constexpr (CPLX) {
+        if constexpr (CPLX && !M3) {
             Frag f0, f1;
             read_chunk(stage, 0, f0);
             read_chunk(stage, 1, f1);
@@ -389,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                 sb += stepB;
                 st_issue = (st_issue + 1 == C_::STAGES) ? 0 : st_issue + 1;
             };
-            if constexpr (CPLX) {
+            if constexpr (CPLX && !M3) {
                 // Software pipeline: all STAGES tiles are requested up front; each K step multiplies chunk 0 from registers
                 // while chunk 1's fragments stream in from LDS, and the barrier that publishes tile kt+1 sits BETWEEN the two
                 // MFMA clusters, so chunk 0 of tile kt+1 is fetched under chunk 1's MFMAs and the stage of tile kt is refilled
@@ -427,8 +449,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                     st = stn;
                 }
             } else {
-                // real: 80 fragment registers would not fit next to the 64 accumulators; one barrier per K step, fragments
-                // fetched at the head of each step (two LDS stages, tile kt+1 in flight)
+                // real (80 fragment registers next to 128 accumulator registers) and 3M (192 accumulator registers) cannot
+                // double-buffer fragments: one barrier per K step, each chunk's fragments fetched right before its MFMAs
                 constexpr int DEPTH = C_::STAGES - 1;
                 issue();
                 if (DEPTH > 1 && nfull > 1) issue();
@@ -445,6 +467,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                     st_comp = (st_comp + 1 == C_::STAGES) ? 0 : st_comp + 1;
                 }
             }
+            if constexpr (!M3) {
             // a partial last K tile goes through the guarded register path into the stage nobody reads any more
             if (nfull * BK < kend - kbeg) {
                 const int st = nfull % C_::STAGES;
@@ -454,9 +477,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                 __syncthreads();
                 compute(st);
             }
+            }
             done = true;
         }
     }
+    if constexpr (!M3) {      // M3 launches are only made when every workgroup takes the LDS-DMA path (host check)
     if (!done && nkt > 0) {
         load_tile(kbeg);
         store_tile(0);
@@ -470,6 +495,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
         }
     }
 
+    }
     // ---- epilogue -----------------------------------------------------------------------------------------------
     // accumulator element: D[row = q + 4g -> N index][col = c16 -> M index]
     // raw blocks store the unscaled partial tile into their slab (tile-local coordinates, ld = BM, no bounds)
@@ -485,6 +511,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
         if (j >= jv) continue;                      // nothing accumulated there (tail_reduce never reads those columns)
         #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            // keep the C reads of one accumulator register group together: hoisting all 32 groups' loads above the stores
+            // would need more registers than the accumulators leave
+            __builtin_amdgcn_sched_barrier(0);
             const int gj = scol0 + wcol + 16 * j + q + 4 * g;
             if (gj >= n_e) continue;
             if constexpr (CPLX) {
@@ -493,7 +522,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                     const int gi = srow0 + wrow + 16 * i + c16;
                     if (gi >= m_e) continue;
                     double* c = Cb + ((long)gj * ldc_e + gi) * 2;
-                    const double xr = acc[0][j][i][g], xi = acc[1][j][i][g];
+                    double xr, xi;
+                    if constexpr (M3) {
+                        const double p1 = acc[0][j][i][g], p2 = acc[1][j][i][g], p3 = acc[NACC - 1][j][i][g];
+                        xr = OPA_C ? p1 + p2 : p1 - p2;
+                        xi = OPA_C ? (p3 - p1) + p2 : (p3 - p1) - p2;
+                    } else { xr = acc[0][j][i][g]; xi = acc[1][j][i][g]; }
                     d2_t out;
                     if (raw) { out = d2_t{xr, xi}; }
                     else {
@@ -613,12 +647,31 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
     const bool ragged = (a.gn * C_::BN - n) >= 16;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
-    if (ragged) hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG, true>), dim3(grid), dim3(256), lds_bytes, st, a);
-    else        hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG, false>), dim3(grid), dim3(256), lds_bytes, st, a);
+    // filter-phase complex products (TAG = 1) run the 3-product scheme unless CHASE_HIP_GEMM3M=0
+    constexpr bool CAN3M = CPLX && TAG == 1;
+    static const bool want3m = [] { const char* e = getenv("CHASE_HIP_GEMM3M"); return e ? atoi(e) != 0 : true; }();
+    // the 3M instantiation has no register-staged fallback: whole row tiles, whole K tiles, 16-byte addressable operands
+    const bool ok3m = want3m && a.glds_ok && (m % C_::BM == 0) && (k % C_::BK == 0) && (kchunk % C_::BK == 0);
+    if constexpr (CAN3M) {
+        static bool attr3 = false;
+        if (!attr3) {
+            (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, false, CAN3M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, true, CAN3M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            attr3 = true;
+        }
+        if (ok3m) {
+            if (ragged) hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG, true, CAN3M>), dim3(grid), dim3(256), lds_bytes, st, a);
+            else        hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG, false, CAN3M>), dim3(grid), dim3(256), lds_bytes, st, a);
+        }
+    }
+    if (!(CAN3M && ok3m)) {
+        if (ragged) hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG, true, false>), dim3(grid), dim3(256), lds_bytes, st, a);
+        else        hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG, false, false>), dim3(grid), dim3(256), lds_bytes, st, a);
+    }
     if (tail > 0) {
         hipLaunchKernelGGL((tail_reduce_kernel<CPLX, C_::BM, C_::BN>), dim3((unsigned)tail), dim3(256), 0, st, ws,
                            (int)full, sk, a.gn, m, n, C, ldc, a.alpha_re, a.alpha_im, a.beta_re, a.beta_im);

@@ -66,6 +66,10 @@ int chase_hip_gemm_d(chase_hip_ctx* ctx, char opA, int m, int n, int k, double a
 int chase_hip_gemm_z(chase_hip_ctx* ctx, char opA, int m, int n, int k, const double alpha[2], const void* A,
                      long lda, const void* B, long ldb, const double beta[2], void* C, long ldc);
 
+/* 1 when complex products issued in the filter phase (chase_hip_ctx_set_phase(ctx, 1)) use the three-multiplication scheme
+ * (default; CHASE_HIP_GEMM3M=0 selects the four-multiplication kernel).  It applies to launches with m a multiple of 128,
+ * k a multiple of 8 and 16-byte addressable operands; other shapes take the four-multiplication kernel. */
+int chase_hip_gemm3m_enabled(void);
 /* register-resident v_mfma_f64_16x16x4_f64 issue-rate probe: returns achieved TFLOP/s */
 int chase_hip_mfma_f64_peak(chase_hip_ctx* ctx, double* tflops);
 /* streaming-copy probe: achieved HBM GB/s for a bytes-sized device-to-device float4 copy */

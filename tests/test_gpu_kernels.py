@@ -43,6 +43,36 @@ def test_gemm_matches_numpy(ctx, cplx, op, shape):
             d.free()
 
 
+@pytest.mark.parametrize("op", ["N", "C"])
+@pytest.mark.parametrize("shape", [(256, 64, 512), (256, 70, 512), (384, 133, 1024), (128, 200, 4096), (2048, 320, 2048),
+                                   (130, 64, 512), (256, 64, 516)])
+def test_filter_phase_gemm_3m_matches_numpy(ctx, op, shape):
+    """Products issued between FilterPhaseStart/End (phase 1) use the three-multiplication complex scheme when the shape
+    allows it (whole 128-row tiles, K a multiple of 8) and the four-multiplication kernel otherwise (last two shapes);
+    both must meet the same componentwise bound, whole and ragged widths, K-split tails, beta != 0."""
+    from chase_amd.capi import lib
+    m, n, k = shape
+    rng = np.random.default_rng(77 + m + 3 * n + 7 * k)
+    A = rnd(rng, (m, k) if op == "N" else (k, m), True)
+    B = rnd(rng, (k, n), True)
+    Cm = rnd(rng, (m, n), True)
+    alpha = 0.7 - 0.3j
+    opA = A if op == "N" else A.conj().T
+    lib.chase_hip_ctx_set_phase(ctx.h, 1)
+    try:
+        for beta in (0.0, -0.4 + 0.2j):
+            dA, dB, dC = ctx.array(A), ctx.array(B), ctx.array(Cm)
+            ctx.gemm(op, m, n, k, alpha, dA.ptr, dA.ld, dB.ptr, dB.ld, beta, dC.ptr, dC.ld, True)
+            got = dC.download()
+            ref = alpha * (opA @ B) + beta * Cm
+            scale = abs(alpha) * (np.abs(opA) @ np.abs(B)) + abs(beta) * np.abs(Cm)
+            assert np.max(np.abs(got - ref) / scale) < 4 * GEMM_TOL
+            for d in (dA, dB, dC):
+                d.free()
+    finally:
+        lib.chase_hip_ctx_set_phase(ctx.h, 0)
+
+
 def test_gemm_beta_zero_ignores_nan_in_c(ctx):
     rng = np.random.default_rng(0)
     A, B = rnd(rng, (64, 32), False), rnd(rng, (32, 16), False)
