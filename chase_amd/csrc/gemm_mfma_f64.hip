@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(const double* __restri
 template <bool CPLX, bool OPA_C, int TAG>
 static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* alpha, const double* A, long lda,
                             const double* B, long ldb, const double* beta, double* C, long ldc,
-                            double* ws, size_t ws_bytes, int num_cu)
+                            double* ws, size_t ws_bytes, int num_cu, bool allow3m)
 {
     using C_ = Cfg<CPLX, OPA_C>;
     if (m <= 0 || n <= 0) return 0;
@@ -651,11 +651,12 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
         (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
-    // filter-phase complex products (TAG = 1) run the 3-product scheme unless CHASE_HIP_GEMM3M=0
-    constexpr bool CAN3M = CPLX && TAG == 1;
+    // complex HEMMs of the filter phase (tag 1) and the Rayleigh-Ritz / residual HEMMs (tag 2) run the 3-product scheme
+    // unless CHASE_HIP_GEMM3M=0; Gram products, back-transforms and everything small stay on four products (tag 0)
+    constexpr bool CAN3M = CPLX;
     static const bool want3m = [] { const char* e = getenv("CHASE_HIP_GEMM3M"); return e ? atoi(e) != 0 : true; }();
     // the 3M instantiation has no register-staged fallback: whole row tiles, whole K tiles, 16-byte addressable operands
-    const bool ok3m = want3m && a.glds_ok && (m % C_::BM == 0) && (k % C_::BK == 0) && (kchunk % C_::BK == 0);
+    const bool ok3m = allow3m && want3m && a.glds_ok && (m % C_::BM == 0) && (k % C_::BK == 0) && (kchunk % C_::BK == 0);
     if constexpr (CAN3M) {
         static bool attr3 = false;
         if (!attr3) {
@@ -686,7 +687,7 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
 template <bool CPLX, bool OPA_C, int TAG>
 static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha, const double* A, long lda,
                        const double* B, long ldb, const double* beta, double* C, long ldc,
-                       double* ws, size_t ws_bytes, int num_cu)
+                       double* ws, size_t ws_bytes, int num_cu, bool allow3m)
 {
     using C_ = Cfg<CPLX, OPA_C>;
     constexpr int EPT = C_::EPT;
@@ -694,12 +695,12 @@ static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha,
     const bool balanced = (C_::WAVES_N == 1);          // all waves span the tile width: skipped groups cost nobody
     if (balanced && n > C_::BN && rem != 0 && rem <= C_::BN - 16 && ws != nullptr) {
         const int n1 = n - rem;
-        int rc = launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n1, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu);
+        int rc = launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n1, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, allow3m);
         if (rc) return rc;
         return launch_gemm_part<CPLX, OPA_C, TAG>(st, m, rem, k, alpha, A, lda, B + (long)n1 * ldb * EPT, ldb, beta,
-                                                  C + (long)n1 * ldc * EPT, ldc, ws, ws_bytes, num_cu);
+                                                  C + (long)n1 * ldc * EPT, ldc, ws, ws_bytes, num_cu, allow3m);
     }
-    return launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu);
+    return launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, allow3m);
 }
 
 int gemm_f64(hipStream_t st, bool cplx, char opA, int m, int n, int k, const double* alpha, const double* A, long lda,
@@ -708,8 +709,8 @@ int gemm_f64(hipStream_t st, bool cplx, char opA, int m, int n, int k, const dou
 {
     const bool opc = (opA == 'C' || opA == 'c' || opA == 'T' || opA == 't');
 #define CHASE_GEMM_DISPATCH(CP, OC)                                                                                    \
-    (tag == 1 ? launch_gemm<CP, OC, 1>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu)         \
-              : launch_gemm<CP, OC, 0>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu))
+    (tag == 1 ? launch_gemm<CP, OC, 1>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, true)   \
+              : launch_gemm<CP, OC, 0>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, tag == 2))
     if (!cplx) return opc ? CHASE_GEMM_DISPATCH(false, true) : CHASE_GEMM_DISPATCH(false, false);
     return opc ? CHASE_GEMM_DISPATCH(true, true) : CHASE_GEMM_DISPATCH(true, false);
 #undef CHASE_GEMM_DISPATCH

@@ -239,7 +239,9 @@ public:
         flush_swaps();
         T* Q = dV1_ + locked_ * N_;
         T* W = dV2_ + locked_ * N_;
+        chase_hip_ctx_set_phase(ctx_, 2);                                           // H-times-block product outside the filter
         gemm('C', N_, block, N_, T(1), dH_, ldd_h_, Q, N_, T(0), W, N_);          // W = H^H Q
+        chase_hip_ctx_set_phase(ctx_, 0);
         gemm('C', block, block, N_, T(1), W, N_, Q, N_, T(0), dA_, block);         // A = W^H Q
         hip_ok(chase_hip_heevd(ctx_, CP, (int)block, dA_, (long)block, ritzv), "heevd");
         hv_valid_ = false;
@@ -262,7 +264,11 @@ public:
         T* V = dV1_ + locked_ * N_;
         T* W = dV2_ + locked_ * N_;
         if (hv_valid_ && hv_locked_ == locked_ && hv_block_ == sub) W = dHV_ + locked_ * N_;   // H V left behind by RR
-        else gemm('N', N_, sub, N_, T(1), dH_, ldd_h_, V, N_, T(0), W, N_);
+        else {
+            chase_hip_ctx_set_phase(ctx_, 2);
+            gemm('N', N_, sub, N_, T(1), dH_, ldd_h_, V, N_, T(0), W, N_);
+            chase_hip_ctx_set_phase(ctx_, 0);
+        }
         hv_valid_ = false;
         hip_ok(chase_hip_resid_norms(ctx_, CP, (int)N_, (int)sub, W, (long)N_, V, (long)N_, ritzv, resd, 0), "resid");
         if (resd != resid_.data() + locked_) std::memcpy(resid_.data() + locked_, resd, sub * sizeof(R));

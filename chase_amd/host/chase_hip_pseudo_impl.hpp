@@ -203,7 +203,9 @@ public:
         T* W = dV2_ + locked_ * N_;
         T* A = dA_;
         T* M = dA_ + n * n;
+        chase_hip_ctx_set_phase(ctx_, 2);
         gemm('N', N_, n, N_, T(1), dH_, ldd_h_, Q, N_, T(0), W, N_);                      // W = H Q
+        chase_hip_ctx_set_phase(ctx_, 0);
         hip_ok(chase_hip_scale_rows(ctx_, CP, (int)N_, (int)n, W, (long)N_, (int)k, -1.0), "flip");   // W = S H Q
         gemm('C', n, n, N_, T(1), Q, N_, W, N_, T(0), A, n);                              // A = Q^H S H Q
         hip_ok(chase_hip_set_identity(ctx_, CP, (int)n, M, (long)n), "identity");
@@ -222,7 +224,9 @@ public:
         const std::size_t sub = nevex_ - locked_;
         T* V = dV1_ + locked_ * N_;
         T* W = dV2_ + locked_ * N_;
+        chase_hip_ctx_set_phase(ctx_, 2);
         gemm('N', N_, sub, N_, T(1), dH_, ldd_h_, V, N_, T(0), W, N_);
+        chase_hip_ctx_set_phase(ctx_, 0);
         hip_ok(chase_hip_resid_norms(ctx_, CP, (int)N_, (int)sub, W, (long)N_, V, (long)N_, ritzv, resd, 0), "resid");
         if (resd != resid_.data() + locked_) std::memcpy(resid_.data() + locked_, resd, sub * sizeof(R));
     }

@@ -265,7 +265,9 @@ public:
         // replicas of V over the grid columns are re-synchronised like the reference does (pchase_gpu.hpp:1631-1633)
         coll(chase_hip_grid_bcast(grid_, CHASE_HIP_ROW, dV1_ + c0 * m_, m_ * block * E, 0, 0));
         hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)block, dV1_ + c0 * m_, (long)m_, dV2_ + c0 * m_, (long)m_), "lacpy");
+        chase_hip_ctx_set_phase(ctx_, 2);                                    // H-times-block product outside the filter
         hemm_dir(true, c0, block, T(1), T(0), false);                        // W1 = H^H V1 (row-type), all-reduced
+        chase_hip_ctx_set_phase(ctx_, 0);
         redistribute_c2r(dV2_ + c0 * m_, dW2_ + c0 * n_, block);             // W2 = V2 in the row-type layout
         gemm('C', block, block, n_, T(1), dW2_ + c0 * n_, n_, dW1_ + c0 * n_, n_, T(0), dA_, block);
         allreduce_packed_upper(dA_, block, CHASE_HIP_ROW);
@@ -294,7 +296,9 @@ public:
         if (hv_valid_ && hv_locked_ == locked_ && hv_block_ == sub) {        // left behind by RR
             HV = dW3_ + c0 * n_; Vr = dW1_ + c0 * n_;
         } else {
+            chase_hip_ctx_set_phase(ctx_, 2);
             hemm_dir(true, c0, sub, T(1), T(0), false);                      // W1 = H^H V1
+            chase_hip_ctx_set_phase(ctx_, 0);
             redistribute_c2r(dV2_ + c0 * m_, dW2_ + c0 * n_, sub);           // W2 = V2 (== V1) row-type
             HV = dW1_ + c0 * n_; Vr = dW2_ + c0 * n_;
         }

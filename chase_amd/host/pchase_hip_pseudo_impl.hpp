@@ -139,7 +139,9 @@ public:
         T* M = this->dA_ + n * n;
         P::coll(chase_hip_grid_bcast(this->grid_, CHASE_HIP_ROW, V1, m * n * E, 0, 0));
         lacpy(n, V1, V2);
+        chase_hip_ctx_set_phase(this->ctx_, 2);
         this->hemm_ptr(true, this->dV1_, this->dW1_, c0, n, T(1), T(0), false);          // W1 = H Q      (row-type)
+        chase_hip_ctx_set_phase(this->ctx_, 0);
         this->redistribute_c2r(V2, W2, n);                                                // W2 = Q        (row-type)
         this->flip_rowtype(W1, n);                                                        // W1 = S H Q
         this->gemm('C', n, n, nl, T(1), W2, nl, W1, nl, T(0), A, n);                      // A = Q^H S H Q

@@ -66,7 +66,7 @@ int chase_hip_gemm_d(chase_hip_ctx* ctx, char opA, int m, int n, int k, double a
 int chase_hip_gemm_z(chase_hip_ctx* ctx, char opA, int m, int n, int k, const double alpha[2], const void* A,
                      long lda, const void* B, long ldb, const double beta[2], void* C, long ldc);
 
-/* 1 when complex products issued in the filter phase (chase_hip_ctx_set_phase(ctx, 1)) use the three-multiplication scheme
+/* 1 when complex products issued in phases 1 and 2 (chase_hip_ctx_set_phase) use the three-multiplication scheme
  * (default; CHASE_HIP_GEMM3M=0 selects the four-multiplication kernel).  It applies to launches with m a multiple of 128,
  * k a multiple of 8 and 16-byte addressable operands; other shapes take the four-multiplication kernel. */
 int chase_hip_gemm3m_enabled(void);
@@ -76,7 +76,9 @@ int chase_hip_mfma_f64_peak(chase_hip_ctx* ctx, double* tflops);
 int chase_hip_hbm_copy_peak(chase_hip_ctx* ctx, size_t bytes, double* gbps);
 
 /* phase 1 = inside FilterPhaseStart/End: GEMMs are launched through the filter-tagged kernel symbol so that rocprofv3
- * reports the Chebyshev-filter HEMM separately (numerics identical); 0 = everything else */
+ * reports the Chebyshev-filter HEMM separately; phase 2 = an H-times-block product outside the filter (Rayleigh-Ritz,
+ * residuals): ordinary symbol.  Complex products of phases 1 and 2 may use the three-multiplication scheme (see
+ * chase_hip_gemm3m_enabled); 0 = everything else (always four multiplications) */
 int chase_hip_ctx_set_phase(chase_hip_ctx* ctx, int phase);
 
 /* ---- on-device input generators (global-index addressed, shard-safe) ------------------------------------------ */
