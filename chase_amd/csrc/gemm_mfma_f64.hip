@@ -256,8 +256,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
         const d2_t* sA = lds + stage * C_::STAGE_UNITS;
         const d2_t* sB = sA + C_::A_UNITS;
         const int ku = 4 * ch + q;
-        #pragma unroll
-        for (int j = 0; j < TN; ++j) f.b[j] = sB[kidx(wcol + 16 * j + c16, ku)];
+        // A fragments first: LDS returns in order, so the first MFMA can start after three reads instead of five
         if constexpr (CPLX || OPA_C) {
             #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -267,7 +266,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                 else                 v = sA[ku * UM + r];
                 f.a[i][0] = v.x; f.a[i][1] = v.y;
             }
+            #pragma unroll
+            for (int j = 0; j < TN; ++j) f.b[j] = sB[kidx(wcol + 16 * j + c16, ku)];
         } else {
+            #pragma unroll
+            for (int j = 0; j < TN; ++j) f.b[j] = sB[kidx(wcol + 16 * j + c16, ku)];
             // real, M-contiguous A: unit = rows (2u, 2u+1) at one k; MFMA step s uses k = 8*ch + 2*q + s
             #pragma unroll
             for (int pr = 0; pr < TM / 2; ++pr)
