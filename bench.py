@@ -58,6 +58,18 @@ def mfma_executed_fraction(cplx, m_loc, k_loc):
     return 1.0
 
 
+def spectrum_check(lam, N, nev):
+    """Full-size parity property: the unperturbed Clement-type matrix has the exact spectrum {-N, -N+2, ..., N}
+    (SURVEY.md §8c), the 1e-6 dense Hermitian perturbation moves an eigenvalue by O(1e-6) (first order: eps * v^H G v), and
+    the bench matrix is that matrix times MATRIX_SCALE / N.  Returns the largest deviation of the nev computed
+    eigenvalues from the analytic ones and the bound it must meet."""
+    scale = MATRIX_SCALE / N
+    exact = scale * (-N + 2.0 * np.arange(nev))
+    dev = float(np.max(np.abs(np.sort(np.asarray(lam)[:nev]) - exact)))
+    tol = 50.0 * MATRIX_PERTURB * scale
+    return {"max_abs_dev_from_analytic": dev, "bound": tol, "ok": bool(dev <= tol)}
+
+
 def cpu_baseline(N, cplx, ncols, budget_s=25.0):
     """Times the CPU oracle's filter HEMM (oracle/chase_oracle.py: OracleCPU.HEMM -> numpy/OpenBLAS gemm) on a bounded
     sample of the same workload: full-height H, as many columns as fit the time budget."""
@@ -123,7 +135,8 @@ def run_single(args):
     # parity guard inside the bench: the timed solves must have converged to the solver tolerance
     resid = s.resid()[:nev]
     lam = s.ritzv[:nev].copy()
-    ok = bool(np.all(np.isfinite(lam)) and np.max(resid) < 1e-8 and stats[-1]["locked"] >= nev)
+    spec = spectrum_check(lam, N, nev)
+    ok = bool(np.all(np.isfinite(lam)) and np.max(resid) < 1e-8 and stats[-1]["locked"] >= nev and spec["ok"])
     last = stats[-1]
     out = {
         "metric": "chebyshev_filter_hemm_gflops", "value": gflops, "unit": "GFLOP/s",
@@ -136,7 +149,7 @@ def run_single(args):
         "eigenpairs_per_sec": nev / (wall / args.steps),
         "pct_fp64_mfma_peak": 100.0 * xf * gflops / 1e3 / FP64_MFMA_PEAK_TFLOPS,
         "mfma_executed_fraction": xf,
-        "converged": ok, "max_resid": float(np.max(resid)),
+        "converged": ok, "max_resid": float(np.max(resid)), "spectrum_check": spec,
         "iterations": last["iterations"], "filtered_vecs_per_solve": vecs / args.steps,
         "phase_seconds_last_solve": {k: last[k] for k in ("t_all", "t_init", "t_lanczos", "t_filter", "t_qr", "t_rr", "t_resid")},
         "device": info["name"],

@@ -71,7 +71,8 @@ def run_distributed(args):
     m_loc, n_loc = rl.count(myrow), cl.count(mycol)
     xf = B.mfma_executed_fraction(cplx, m_loc, n_loc) if (m_loc % 128 == 0 and n_loc % 128 == 0) else 1.0
     resid = s.resid()[:nev]
-    ok = bool(np.max(resid) < 1e-8 and stats[-1]["locked"] >= nev)
+    spec = None if pseudo else B.spectrum_check(s.ritzv[:nev], N, nev)
+    ok = bool(np.max(resid) < 1e-8 and stats[-1]["locked"] >= nev and (spec is None or spec["ok"]))
     last = stats[-1]
     out = None
     if rank == 0:
@@ -90,7 +91,7 @@ def run_distributed(args):
             "eigenpairs_per_sec": nev / (wall / args.steps),
             "pct_fp64_mfma_peak": 100.0 * xf * gflops / 1e3 / world / B.FP64_MFMA_PEAK_TFLOPS,
             "mfma_executed_fraction": xf,
-            "converged": ok, "max_resid": float(np.max(resid)),
+            "converged": ok, "max_resid": float(np.max(resid)), "spectrum_check": spec,
             "iterations": last["iterations"], "filtered_vecs_per_solve": vecs / args.steps,
             "phase_seconds_last_solve": {k: last[k] for k in ("t_all", "t_init", "t_lanczos", "t_filter", "t_qr", "t_rr", "t_resid")},
             "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<cplx,op,TAG=1> (filter HEMM, per GPU)",
