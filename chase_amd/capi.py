@@ -64,6 +64,7 @@ _sig("chase_hip_gemm_z", c_int, c_void_p, c_char, c_int, c_int, c_int, P(c_doubl
      c_long, P(c_double), c_void_p, c_long)
 _sig("chase_hip_mfma_f64_peak", c_int, c_void_p, P(c_double))
 _sig("chase_hip_gemm3m_enabled", c_int)
+_sig("chase_hip_host_lapack_warmup", c_int)
 _sig("chase_hip_hbm_copy_peak", c_int, c_void_p, c_size_t, P(c_double))
 
 

@@ -58,6 +58,31 @@ const char* chase_hip_lapack_provider(void)
     lapack_bind(nullptr);
     return lapack_provider();
 }
+/* binds the provider and runs tiny problems through the routines the hot path uses, so that the library's lazily loaded
+ * compute kernels (MKL: seconds on a cold page cache) are resident before the first solve */
+int chase_hip_host_lapack_warmup(void)
+{
+    int rc = lapack_bind(nullptr);
+    if (rc) return rc;
+    static bool done = false;
+    if (done) return 0;
+    const int n = 8;
+    double d[n], e[n], w[n], Z[n * n];
+    for (int i = 0; i < n; ++i) { d[i] = i; e[i] = 0.5; }
+    rc = host_stedc(n, d, e, w, Z, n);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) { d[i] = i; e[i] = 0.5; }
+    rc = host_stemr(n, d, e, w, Z, n);
+    if (rc) return rc;
+    double A[2 * n * n];
+    for (int i = 0; i < 2 * n * n; ++i) A[i] = 0.0;
+    for (int i = 0; i < n; ++i) A[2 * (i + i * n)] = 1.0 + i;
+    rc = host_heevd(true, n, A, n, w);
+    if (rc) return rc;
+    done = true;
+    return 0;
+}
+
 int chase_hip_set_host_threads(int n)
 {
     lapack_bind(nullptr);

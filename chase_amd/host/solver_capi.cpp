@@ -60,6 +60,7 @@ int chase_hip_solver_create(chase_hip_solver** out, chase_hip_ctx* ctx, int cplx
     if (!out || !ctx || !H || !V || !ritzv) return chase_hip::set_error(CHASE_HIP_EINVAL, "solver_create: NULL argument");
     auto s = std::make_unique<chase_hip_solver>();
     s->cplx = cplx ? 1 : 0;
+    chase_hip_host_lapack_warmup();          // not fatal here: a missing provider is reported by the first LAPACK call
     int rc = guarded("solver_create", [&] {
         if (cplx) {
             auto* p = new ChaseHip<zc>(ctx, N, nev, nex, (zc*)H, ldh, (zc*)V, ldv, ritzv, h_on_device != 0);
@@ -82,6 +83,7 @@ int chase_hip_solver_create_pseudo(chase_hip_solver** out, chase_hip_ctx* ctx, i
     auto s = std::make_unique<chase_hip_solver>();
     s->cplx = cplx ? 1 : 0;
     s->pseudo = 1;
+    chase_hip_host_lapack_warmup();          // not fatal here: a missing provider is reported by the first LAPACK call
     int rc = guarded("solver_create_pseudo", [&] {
         if (cplx) {
             auto* p = new ChaseHipPseudo<zc>(ctx, N, nev, nex, (zc*)H, ldh, (zc*)V, ldv, ritzv, h_on_device != 0);
@@ -103,6 +105,7 @@ int chase_hip_psolver_create(chase_hip_solver** out, chase_hip_ctx* ctx, chase_h
         return chase_hip::set_error(CHASE_HIP_EINVAL, "psolver_create: NULL argument");
     auto s = std::make_unique<chase_hip_solver>();
     s->cplx = cplx ? 1 : 0;
+    chase_hip_host_lapack_warmup();          // not fatal here: a missing provider is reported by the first LAPACK call
     int rc = guarded("psolver_create", [&] {
         if (cplx) {
             auto* p = new pChaseHip<zc>(ctx, grid, N, nev, nex, mb, nb, (zc*)H_loc_dev, ldh, ritzv);
@@ -127,6 +130,7 @@ int chase_hip_psolver_create_pseudo(chase_hip_solver** out, chase_hip_ctx* ctx, 
     auto s = std::make_unique<chase_hip_solver>();
     s->cplx = cplx ? 1 : 0;
     s->pseudo = 1;
+    chase_hip_host_lapack_warmup();          // not fatal here: a missing provider is reported by the first LAPACK call
     int rc = guarded("psolver_create_pseudo", [&] {
         if (cplx) {
             auto* p = new pChaseHipPseudo<zc>(ctx, grid, N, nev, nex, mb, nb, (zc*)H_loc_dev, ldh, ritzv);

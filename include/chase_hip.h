@@ -115,6 +115,9 @@ int chase_hip_save_matrix(chase_hip_ctx* ctx, const char* path, int cplx, int m,
 int chase_hip_set_lapack_lib(const char* path);   /* optional explicit LP64 LAPACK shared library */
 const char* chase_hip_lapack_provider(void);      /* path of the bound provider ("" if none) */
 int chase_hip_set_host_threads(int n);
+/* bind the provider and page its compute kernels in (called by the solver constructors; first use of a cold MKL costs
+ * seconds, which would otherwise land in the first solve) */
+int chase_hip_host_lapack_warmup(void);
 
 /* ---- O(N*n) kernels; cplx = 0 (fp64) or 1 (complex fp64); all matrix pointers are device pointers -------------- */
 /* H[i,i] += shift (real part).  Replaces chase_cpu.hpp:384-389 / cuda/shiftDiagonal.cu:23-50 */
