@@ -74,6 +74,12 @@ int chase_hip_grid_create_rccl(chase_hip_grid** out, chase_hip_ctx* ctx, int npr
         ncclUniqueId u; memcpy(&u, id_col, sizeof u);
         NCCLCHK(ncclCommInitRank(&g->comm[CHASE_HIP_COL], nprow, u, g->myrow));
     }
+    // first collective on a communicator sets up the xGMI connections (hundreds of ms): pay it here, not in the first
+    // filter step, and surface transport problems at construction
+    HIPCHK(hipMemsetAsync(g->scal_dev, 0, 64, g->comm_stream));
+    for (int grp = 0; grp < 2; ++grp)
+        if (g->comm[grp]) NCCLCHK(ncclAllReduce(g->scal_dev, g->scal_dev, 8, ncclDouble, ncclSum, g->comm[grp], g->comm_stream));
+    HIPCHK(hipStreamSynchronize(g->comm_stream));
     *out = g;
     return 0;
 }
