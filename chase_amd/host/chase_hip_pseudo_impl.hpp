@@ -244,13 +244,13 @@ public:
         lanczosIter_ = m; numLanczos_ = 1;
         std::vector<R> theta(m), tau(m), z(m * m);
         lanczos_core(m, 1, false, theta.data(), tau.data(), z.data());
-        (void)upperb;                                         // the pseudo kernel does not produce a bound (lanczos.hpp:522-600)
+        if (upperb) *upperb = theta[m - 1];                   // cpu/lanczos.hpp:629: largest Ritz value of the run
     }
     void Lanczos(std::size_t M, std::size_t numvec, R* upperb, R* ritzv, R* Tau, R* ritzV) override
     {
         lanczosIter_ = M; numLanczos_ = numvec;
         lanczos_core(M, numvec, true, ritzv, Tau, ritzV);
-        (void)upperb;
+        if (upperb) *upperb = ritzv[M - 1];                   // cpu/lanczos.hpp:515
     }
     void LanczosDos(std::size_t idx, std::size_t m, T* ritzVc) override
     {

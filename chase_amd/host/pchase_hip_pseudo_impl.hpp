@@ -159,16 +159,18 @@ public:
         lacpy(n, V1, V2);                                                                 // pchase_cpu.hpp:881-883
     }
 
-    void Lanczos(std::size_t m, R*) override
+    void Lanczos(std::size_t m, R* upperb) override
     {
         this->lanczosIter_ = m; this->numLanczos_ = 1;
         std::vector<R> theta(m), tau(m), z(m * m);
         pseudo_lanczos(m, 1, false, theta.data(), tau.data(), z.data());
+        if (upperb) *upperb = theta[m - 1];                   // mpi/pseudo_hermitian_lanczos.hpp:470
     }
-    void Lanczos(std::size_t M, std::size_t numvec, R*, R* ritzv, R* Tau, R* ritzV) override
+    void Lanczos(std::size_t M, std::size_t numvec, R* upperb, R* ritzv, R* Tau, R* ritzV) override
     {
         this->lanczosIter_ = M; this->numLanczos_ = numvec;
         pseudo_lanczos(M, numvec, true, ritzv, Tau, ritzV);
+        if (upperb) *upperb = ritzv[M - 1];                   // mpi/pseudo_hermitian_lanczos.hpp:295
     }
 
 protected:

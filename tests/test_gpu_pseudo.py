@@ -130,3 +130,28 @@ def test_solve_pseudo_generated_bse_vs_oracle(ctx):
     assert np.max(np.abs(np.sort(lam) - np.sort(k.ritzv[:nev]))) <= 1e-9
     assert abs(st["iterations"] - so["iterations"]) <= 1
     s.close()
+
+
+@pytest.mark.parametrize("tag,N", [("cdouble_tiny_random_BSE", 10), ("cdouble_random_BSE", 200)])
+def test_pseudo_lanczos_reference_assertions_on_gpu(ctx, tag, N):
+    """The reference's pseudo-Hermitian Lanczos tests (tests/linalg/internal/cpu/pseudo_hermitian_lanczos.cpp:95-199,
+    cuda/pseudo_hermitian_lanczos.cpp) through the HIP Impl's Lanczos virtuals, same fixtures and assertions."""
+    import os
+    from conftest import REF_FIX
+    from chase_amd.capi import PseudoSolver
+    from oracle import chase_oracle as O
+    H = read_ref_matrix(tag + ".bin", N, N, True)
+    eigs = np.fromfile(os.path.join(REF_FIX, "eigs_%s.bin" % tag), dtype=np.complex128).real
+    s = PseudoSolver(ctx, H, N // 2 - N // 4, N // 4)        # 2 (nev + nex) = N columns hold the M = N Krylov vectors
+    s.Start()
+    s.V[:] = O.random_start_vectors(N, N, True)
+    s.initVecs(False)
+    ub, theta, tau, ritzV = s.Lanczos(N, 1)
+    eps = np.finfo(np.float64).eps
+    assert (theta[0] - eigs[0]) ** 2 < 1e3 * eps and (theta[N - 1] - eigs[N - 1]) ** 2 < 1e3 * eps
+    assert ub == theta[N - 1]
+    s.V[:] = O.random_start_vectors(N, N, True)
+    s.initVecs(False)
+    ub1 = s.Lanczos(N, 0)
+    assert (ub1 >= eigs[N - 1] or abs(ub1 - eigs[N - 1]) / abs(eigs[N - 1]) <= 1e-2) and ub1 < 5 * eigs[N - 1]
+    s.close()

@@ -119,3 +119,24 @@ def test_pseudo_hermitian_oracle_on_reference_bse_fixture():
     assert np.max(k.resid[:20]) <= 1e-10
     assert np.max(O.residuals(H, k.ritzv[:20], k.V1[:, :20])) <= 1e-10
     assert np.max(np.abs(k.ritzv[:20] - pos[:20])) <= 1e-10
+
+
+@pytest.mark.parametrize("tag,N", [("cdouble_tiny_random_BSE", 10), ("cdouble_random_BSE", 200)])
+def test_pseudo_lanczos_reference_assertions(tag, N):
+    """tests/linalg/internal/cpu/pseudo_hermitian_lanczos.cpp:95-199 on the reference's own fixtures: full-length
+    S-inner-product Lanczos (M = N, one vector, mt19937(1337) start block) reproduces the extreme eigenvalues to
+    diff^2 < 1e3 eps, and the bound of the single-vector overload lies in [0.99, 5) x the largest eigenvalue."""
+    import os
+    from conftest import REF_FIX
+    H = read_ref_matrix(tag + ".bin", N, N, True)
+    eigs = np.fromfile(os.path.join(REF_FIX, "eigs_%s.bin" % tag), dtype=np.complex128).real
+    k = O.OraclePseudoCPU(H, N // 2 - N // 4, N // 4)
+    k.Start()
+    k.V1 = O.random_start_vectors(N, N, True)
+    ub, theta, tau, ritzV = k.Lanczos(N, 1)
+    eps = np.finfo(np.float64).eps
+    assert (theta[0] - eigs[0]) ** 2 < 1e3 * eps and (theta[N - 1] - eigs[N - 1]) ** 2 < 1e3 * eps
+    assert ub == theta[N - 1]
+    k.V1 = O.random_start_vectors(N, N, True)
+    ub1 = k.Lanczos(N)
+    assert (ub1 >= eigs[N - 1] or abs(ub1 - eigs[N - 1]) / abs(eigs[N - 1]) <= 1e-2) and ub1 < 5 * eigs[N - 1]
