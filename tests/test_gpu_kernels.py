@@ -319,3 +319,42 @@ def test_matrix_file_roundtrip_and_shards(ctx, tmp_path, cplx):
         from conftest import REF_FIX
         ref = read_ref_matrix("cdouble_random_BSE.bin", 200, 200, True)
         assert np.array_equal(ctx.load_matrix(os.path.join(REF_FIX, "cdouble_random_BSE.bin"), 200, True).download(), ref)
+
+
+# ---- sign flips / conjugation of the pseudo-Hermitian path ---------------------------------------------------------------
+@pytest.mark.parametrize("cplx", [False, True])
+def test_flip_lower_half_sign_known_answer(ctx, cplx):
+    """tests/linalg/internal/cpu/flipSign.cpp:27-54 (cuda/flipSign.cpp): 10 x 10 of ones, the lower half of every column
+    changes sign, the upper half is untouched — with the sequential kernel and with the block / block-cyclic variant that
+    decides by GLOBAL row index (mpi/flipSign.hpp:20-100)."""
+    from chase_amd.capi import lib, check
+    N = 10
+    one = np.ones((N, N), dtype=np.complex128 if cplx else np.float64, order="F")
+    d = ctx.array(one)
+    check(lib.chase_hip_scale_rows(ctx.h, int(cplx), N, N, d.ptr, N, N // 2, -1.0), "scale_rows")
+    got = d.download()
+    assert np.all(got[: N // 2] == 1) and np.all(got[N // 2:] == -1)
+    # distributed: every rank of a p-rank block / block-cyclic row distribution flips exactly its rows with g >= N/2
+    N = 37
+    for (nb, p) in [(0, 1), (0, 2), (0, 3), (4, 2), (5, 3), (64, 2)]:
+        bl = nb if nb else (N // p if N % p == 0 else N // p + 1)
+        for q in range(p):
+            gl = [g for g in range(N) if (g // bl) % p == q]
+            m = len(gl)
+            if m == 0:
+                continue
+            x = (np.arange(m * 3, dtype=np.float64).reshape(m, 3, order="F") + 1.0).astype(one.dtype)
+            d = ctx.array(np.asfortranarray(x))
+            check(lib.chase_hip_scale_rows_bc(ctx.h, int(cplx), m, 3, d.ptr, m, N // 2, bl, p, q, -1.0), "scale_rows_bc")
+            want = x.copy()
+            want[[i for i, g in enumerate(gl) if g >= N // 2], :] *= -1
+            assert np.array_equal(d.download(), want), (nb, p, q)
+
+
+def test_conj_inplace(ctx):
+    from chase_amd.capi import lib, check
+    rng = np.random.default_rng(9)
+    X = np.asfortranarray(rng.standard_normal((33, 5)) + 1j * rng.standard_normal((33, 5)))
+    d = ctx.array(X)
+    check(lib.chase_hip_conj(ctx.h, 33, 5, d.ptr, 33), "conj")
+    assert np.array_equal(d.download(), X.conj())
