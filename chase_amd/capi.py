@@ -402,6 +402,9 @@ _sig("chase_hip_pseudo_rr_small", c_int, c_void_p, c_int, c_int, c_void_p, c_voi
 _sig("chase_hip_set_identity", c_int, c_void_p, c_int, c_int, c_void_p, c_long)
 
 
+_sig("chase_hip_solver_lanczos_for_h2", c_int, c_void_p, c_int, c_int, P(c_double), P(c_size_t))
+
+
 class PseudoSolver(Solver):
     """ChaseHipPseudo<T>: pseudo-Hermitian (BSE) Impl — subspace of 2*(nev+nex) columns, chase::Solve_pseudo."""
 
@@ -430,6 +433,11 @@ class PseudoSolver(Solver):
 
     def ApplyKconjugate(self, block):
         check(lib.chase_hip_op_kconj(self.h, block), "ApplyKconjugate")
+
+    def lanczos_for_H2(self, numvec, m):
+        ub, idx = c_double(), c_size_t()
+        check(lib.chase_hip_solver_lanczos_for_h2(self.h, numvec, m, C.byref(ub), C.byref(idx)), "lanczos_for_H2")
+        return ub.value, idx.value
 
     def RR(self, block, offset):
         check(lib.chase_hip_op_rr(self.h, self.ritzv.ctypes.data + 8 * offset, block), "RR")

@@ -246,6 +246,25 @@ int chase_hip_solver_solve(chase_hip_solver* s, int record_trace)
     });
 }
 
+/* Algorithm<T>::lanczos_for_H2 (algorithm/algorithm.inc:1217-1373) on a pseudo-Hermitian solver: DoS estimates of the
+ * H^2 spectrum into the solver's ritzv[0 .. nev+nex), upper bound and the number of extracted Ritz directions */
+int chase_hip_solver_lanczos_for_h2(chase_hip_solver* s, int numvec, int m, double* upperb, size_t* idx)
+{
+    if (!s || !upperb || !idx) return chase_hip::set_error(CHASE_HIP_EINVAL, "lanczos_for_h2: NULL argument");
+    if (!s->pseudo) return chase_hip::set_error(CHASE_HIP_EINVAL, "lanczos_for_h2: not a pseudo-Hermitian solver");
+    return guarded("lanczos_for_H2", [&] {
+        if (s->cplx) {
+            auto* k = s->z.get();
+            *idx = Algorithm<zc, ChaseBase<zc>>::lanczos_for_H2(k, (int)k->GetN(), numvec, m, (int)(k->GetNev() + k->GetNex()),
+                                                                 upperb, k->GetRitzv());
+        } else {
+            auto* k = s->d.get();
+            *idx = Algorithm<double, ChaseBase<double>>::lanczos_for_H2(k, (int)k->GetN(), numvec, m,
+                                                                        (int)(k->GetNev() + k->GetNex()), upperb, k->GetRitzv());
+        }
+    });
+}
+
 int chase_hip_solver_stats(chase_hip_solver* s, chase_hip_stats* o)
 {
     if (!s || !o) return chase_hip::set_error(CHASE_HIP_EINVAL, "solver_stats: NULL argument");

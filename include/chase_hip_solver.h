@@ -55,6 +55,10 @@ int chase_hip_solver_destroy(chase_hip_solver* s);
 int chase_hip_solver_set(chase_hip_solver* s, const char* key, double value);
 int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* value);
 int chase_hip_solver_solve(chase_hip_solver* s, int record_trace);
+/* Algorithm<T>::lanczos_for_H2 (algorithm/algorithm.inc:1217-1373; tests/algorithm/lanczos_for_H2_test.cpp) on a
+ * pseudo-Hermitian solver: DoS-based estimates of the H^2 spectrum go to the solver's ritzv[0 .. nev+nex), *upperb = b_sup,
+ * *idx = number of Ritz directions moved into the start block */
+int chase_hip_solver_lanczos_for_h2(chase_hip_solver* s, int numvec, int m, double* upperb, size_t* idx);
 int chase_hip_solver_stats(chase_hip_solver* s, chase_hip_stats* out);
 const double* chase_hip_solver_resid(chase_hip_solver* s); /* nev+nex residuals (host) */
 const char* chase_hip_solver_trace(chase_hip_solver* s);   /* '\n'-separated virtual-call trace of the last solve */

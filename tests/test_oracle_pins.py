@@ -140,3 +140,49 @@ def test_pseudo_lanczos_reference_assertions(tag, N):
     k.V1 = O.random_start_vectors(N, N, True)
     ub1 = k.Lanczos(N)
     assert (ub1 >= eigs[N - 1] or abs(ub1 - eigs[N - 1]) / abs(eigs[N - 1]) <= 1e-2) and ub1 < 5 * eigs[N - 1]
+
+
+def _lanczos_for_H2_reference_assertions(eigs, nevex, m, upperb, idx, ritzv):
+    """tests/algorithm/lanczos_for_H2_test.cpp:103-232: properties of the H^2 bounds on the BSE fixture."""
+    n = len(eigs)
+    e2 = np.sort(eigs ** 2)
+    smallest, largest = e2[0], e2[n - 1]
+    lam_2nevex = e2[2 * nevex - 1] if 2 * nevex - 1 < n else e2[n - 1]
+    assert np.isfinite(upperb) and upperb > 0
+    assert np.all(np.isfinite(ritzv[:nevex])) and np.all(ritzv[:nevex] >= 0)
+    mu_1 = min(ritzv[: nevex - 1])
+    mu_nn = ritzv[nevex - 1]
+    assert 0 < mu_1 < mu_nn
+    gap_low = lam_2nevex - smallest
+    if gap_low > 0:
+        assert abs(mu_1 - smallest) <= 0.2 * gap_low
+    assert mu_nn > 0 and mu_nn >= lam_2nevex and mu_nn <= upperb
+    if abs(mu_nn - largest) > 0:
+        assert abs(mu_nn - lam_2nevex) <= 0.35 * abs(mu_nn - largest)
+    assert 0.98 * largest <= upperb <= 1.02 * largest
+    assert idx <= m
+
+
+def _lanczos_for_H2_start_block(n, nevex, ncol):
+    """per-column generators mt19937(1314521 + j), T(dist(gen), dist(gen)) like the reference test"""
+    V = np.zeros((n, ncol), dtype=np.complex128, order="F")
+    for j in range(nevex):
+        d = O.StdNormal(1314521 + j).draw(2 * n)
+        V[:, j] = d[0::2] + 1j * d[1::2]
+    return V
+
+
+def test_lanczos_for_H2_reference_assertions():
+    import os
+    from conftest import REF_FIX
+    n, nev, nex, numvec, m = 200, 20, 20, 10, 50
+    H = read_ref_matrix("cdouble_random_BSE.bin", n, n, True)
+    eigs = np.fromfile(os.path.join(REF_FIX, "eigs_cdouble_random_BSE.bin"), dtype=np.complex128).real
+    k = O.OraclePseudoCPU(H, nev, nex)
+    k.config.num_lanczos, k.config.lanczos_iter = numvec, m
+    k.Start()
+    k.V1 = _lanczos_for_H2_start_block(n, nev + nex, k.ncol)
+    k.initVecs(False)
+    k.QR(0, 1.0)
+    upperb, idx = O.lanczos_for_H2(k, n, numvec, m, nev + nex, k.ritzv)
+    _lanczos_for_H2_reference_assertions(eigs, nev + nex, m, upperb, idx, k.ritzv)
