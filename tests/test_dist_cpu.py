@@ -34,3 +34,25 @@ def test_block_layout_matches_reference_rule():
     lay = cd.Layout(1001, 64, 2)
     assert [lay.count(0), lay.count(1)] == [512, 489]
     assert cd.grid_shape(8) == (4, 2) and cd.grid_shape(4) == (2, 2) and cd.grid_shape(2) == (2, 1)
+
+
+def test_grid_coordinates_and_shard_shapes_reference_known_answers():
+    """tests/grid/mpiGrid2D.cpp:80-132 (ColMajor 2 x 2: rank -> (row, col) = 0:(0,0) 1:(1,0) 2:(0,1) 3:(1,1)) and
+    tests/matrix/distMatrix.cpp:343-389 (11 x 11, 2 x 2 blocks block-cyclic on 2 x 2: local shapes 6x6, 5x6, 6x5, 5x5)."""
+    from chase_amd import dist as cd
+    assert [cd.coords_of(r, 2) for r in range(4)] == [(0, 0), (1, 0), (0, 1), (1, 1)]
+    rl, cl = cd.Layout(11, 2, 2), cd.Layout(11, 2, 2)
+    shapes = []
+    for r in range(4):
+        i, j = cd.coords_of(r, 2)
+        shapes.append((rl.count(i), cl.count(j)))
+    assert shapes == [(6, 6), (5, 6), (6, 5), (5, 5)]
+    # local <-> global index maps are inverse to each other and partition 0..N-1 (block and block-cyclic)
+    for (N, nb, p) in [(11, 2, 2), (1001, 64, 4), (10, 0, 4), (65536, 64, 4), (37, 5, 3)]:
+        lay = cd.Layout(N, nb, p)
+        seen = []
+        for q in range(p):
+            g = lay.globals_of(q)
+            assert all(lay.owner(int(x)) == q for x in g[:50]) and all(lay.local(int(x)) == l for l, x in enumerate(g[:50]))
+            seen.extend(int(x) for x in g)
+        assert sorted(seen) == list(range(N))
