@@ -66,6 +66,19 @@ def scenario_hemm_kat(ctx, grid, rank, world):
     assert np.all(v[:, :2] == 806.0), v[:, :2]
     assert np.all(v[:, 2:] == 2.0)
     s.close()
+    # tests/linalg/internal/mpi/shiftDiagonal.cpp:31-77: identity (10 x 10) shifted by -5 -> -4 on the diagonal of the
+    # shards that own diagonal entries, exact zeros everywhere else; block layout and block-cyclic nb = 3
+    for mb in (0, 3):
+        rl, cl = cd.Layout(N, mb, grid.nprow), cd.Layout(N, mb, grid.npcol)
+        I = np.eye(N, order="F")
+        dI = ctx.array(cd.local_block_of(I, rl, cl, grid.myrow, grid.mycol))
+        s = cd.DistSolver(ctx, grid, dI, N, 2, 2, False, mb, mb)
+        s.Shift(-5.0)
+        want = cd.local_block_of(I - 5.0 * np.eye(N), rl, cl, grid.myrow, grid.mycol)
+        assert np.array_equal(dI.download(), want)
+        s.Shift(5.0, True)
+        assert np.array_equal(dI.download(), cd.local_block_of(I, rl, cl, grid.myrow, grid.mycol))
+        s.close()
 
 
 def scenario_ops(ctx, grid, rank, world, cplx, mb):
