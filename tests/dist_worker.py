@@ -201,6 +201,43 @@ def scenario_symcheck(ctx, grid, rank, world, cplx, mb):
         s.close()
 
 
+def scenario_qr_fixtures(ctx, grid, rank, world, cplx):
+    """Distributed QR on the reference's own conditioned fixtures (tests/linalg/internal/mpi/cholqr.cpp,
+    householder_qr.cpp; 100 x 50, cond 10 / 1e4 / ill): CholQR1 / CholQR2 / shifted CholQR2 selected by the condition
+    estimate like pChASECPU::QR, potrf failure falling through to Householder, and the Householder path itself."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest
+    N, n = 100, 50
+    pre = "matrix_cdouble_" if cplx else "matrix_double_"
+    rl, cl = cd.Layout(N, 0, grid.nprow), cd.Layout(N, 0, grid.npcol)
+    rows = rl.globals_of(grid.myrow)
+    dH = ctx.array(cd.local_block_of(np.eye(N, dtype=np.complex128 if cplx else np.float64), rl, cl, grid.myrow, grid.mycol))
+
+    def run(name, cond, cholqr=1):
+        V = conftest.read_ref_matrix(pre + name, N, n, cplx)
+        s = cd.DistSolver(ctx, grid, dH, N, n // 2, n - n // 2, cplx)
+        s.set(cholqr=cholqr)
+        s.Start()
+        s.upload_local_V(V[rows, :]); s.initVecs(False)
+        s.QR(0, cond)
+        variant = int(s.get("qr_variant"))
+        objs = [None] * world
+        dist.all_gather_object(objs, (grid.myrow, grid.mycol, s.local_V()))
+        Q = np.zeros_like(V)
+        for (i, j, blk) in objs:
+            if j == 0:
+                Q[rl.globals_of(i), :] = blk
+        s.close()
+        assert np.linalg.norm(V - Q @ (Q.conj().T @ V)) <= 1e-9 * np.linalg.norm(V)       # same column space
+        return variant, O.orthogonality(Q)
+
+    v, o = run("cond_10.bin", 10.0);   assert v == 1 and o <= 15 * EPS + EPS
+    v, o = run("cond_1e4.bin", 1e4);   assert v == 2 and o <= 15 * EPS + EPS
+    v, o = run("cond_ill.bin", 1e12);  assert v in (0, 3) and o <= 25 * EPS                 # shifted CholQR2 or HHQR
+    v, o = run("cond_ill.bin", 10.0);  assert v == 0 and o <= 25 * EPS                      # CholQR1 fails -> Householder
+    v, o = run("cond_1e4.bin", 1e4, cholqr=0); assert v == 0 and o <= 25 * EPS              # Householder requested
+
+
 def bse_fixture():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import conftest
@@ -317,6 +354,8 @@ def main():
         elif scen == "solve":
             N, nev, nex = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
             scenario_solve(ctx, grid, rank, world, N, nev, nex, sys.argv[6] == "z", int(sys.argv[7]), int(sys.argv[8]))
+        elif scen == "qr_fixtures":
+            scenario_qr_fixtures(ctx, grid, rank, world, sys.argv[3] == "z")
         elif scen == "symcheck":
             scenario_symcheck(ctx, grid, rank, world, sys.argv[3] == "z", int(sys.argv[4]))
         elif scen == "pseudo_ops":

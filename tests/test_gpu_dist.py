@@ -70,3 +70,8 @@ def test_pseudo_solve_rccl_single_rank():
 @pytest.mark.parametrize("nranks,typ,mb", [(4, "z", 0), (6, "d", 16), (1, "z", 0)])
 def test_distributed_symmetry_check(nranks, typ, mb):
     run_ranks(nranks, "host", "symcheck", typ, mb)
+
+
+@pytest.mark.parametrize("nranks,typ", [(4, "z"), (2, "d")])
+def test_distributed_qr_on_reference_fixtures(nranks, typ):
+    run_ranks(nranks, "host", "qr_fixtures", typ)
