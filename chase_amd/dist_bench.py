@@ -31,6 +31,10 @@ def run_distributed(args):
     pg = cd.make_process_groups(nprow, npcol)
     transport = os.environ.get("CHASE_HIP_TRANSPORT", "rccl")
     grid = cd.Grid(ctx, nprow, npcol, rank, transport=transport, pg=pg)
+    # RCCL prints a version banner through C stdio at communicator creation; push it out NOW on every rank so that the
+    # JSON line rank 0 prints at the end is the last line of the job's stdout
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
     mb = nb = args.block_cyclic if args.block_cyclic >= 0 else B.DEFAULT_BLOCK_CYCLIC.get(workload, 0)
     rl, cl = cd.Layout(N, mb, nprow), cd.Layout(N, nb, npcol)
     pseudo = workload in B.PSEUDO_WORKLOADS
@@ -107,6 +111,7 @@ def run_distributed(args):
     s.close()
     grid.close()
     ctx.close()
+    ctypes.CDLL(None).fflush(None)
     dist.barrier()
     dist.destroy_process_group()
     return out

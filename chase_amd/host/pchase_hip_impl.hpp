@@ -85,6 +85,7 @@ public:
         alloc((void**)&dPack_, pack_elems_ * sizeof(T));
         // staging must hold the largest block of ANY rank (rank 0 of a dimension owns the most rows)
         alloc((void**)&dStage_, (std::size_t)std::max(Rr_.count(0), Cc_.count(0)) * nc_ * sizeof(T));
+        dHbac_ = dH_; ldhbac_ = ldh_;
         build_diag_lists();
         build_redistribution();
     }
@@ -124,11 +125,11 @@ public:
             for (auto& x : h) x = rnd(d, gen);
             hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)m_, 1, h.data(), (long)m_, v, (long)m_), "upload v");
             redistribute_c2r(v, v2, 1);
-            const bool pseudo = pseudo_;
-            pseudo_ = false;                                   // the plain products, whatever the matrix type
+            const T* keep = dHbac_; const std::size_t keep_ld = ldhbac_;
+            dHbac_ = dH_; ldhbac_ = ldh_;                      // the plain products, whatever the matrix type
             hemm_ptr(true, v, u, 0, 1, T(1), T(0), false);
             hemm_ptr(false, v2, uT, 0, 1, T(1), T(0), false);
-            pseudo_ = pseudo;
+            dHbac_ = keep; ldhbac_ = keep_ld;
             redistribute_r2c(u, ucol, 1);
             hip_ok(chase_hip_download_matrix(ctx_, CP, (int)m_, 1, ucol, (long)m_, hu.data(), (long)m_), "download");
             hip_ok(chase_hip_download_matrix(ctx_, CP, (int)m_, 1, uT, (long)m_, hut.data(), (long)m_), "download");
@@ -446,8 +447,10 @@ protected:
     {
         hemm_ptr(bAc, bAc ? dV1_ : dW1_, bAc ? dW1_ : dV1_, c0, nc, alpha, beta, pipelined);
     }
-    // in: column-type (bAc) / row-type (cAb) block, out: the other type.  For a pseudo-Hermitian H the bAc product is
-    // wrapped in sign flips of the global lower half, H V = S H^H S V (mpi/hemm.hpp:125-199); cAb is H W as it stands.
+    // in: column-type (bAc) / row-type (cAb) block, out: the other type.  bAc multiplies with dHbac_: H_loc itself for a
+    // Hermitian matrix; the pseudo-Hermitian Impl points it at G_loc = S H_loc S (signs of the two off-diagonal quadrants
+    // flipped), because H V = S H^H S V (mpi/hemm.hpp:125-199) = G^H V — the reference's four vector sign flips around
+    // the conj-transposed GEMM are folded into the matrix once, and the panel pipeline applies unchanged.  cAb is H W.
     void hemm_ptr(bool bAc, T* in, T* out, std::size_t c0, std::size_t nc, T alpha, T beta, bool pipelined)
     {
         const int group = bAc ? CHASE_HIP_COL : CHASE_HIP_ROW;
@@ -455,27 +458,20 @@ protected:
         const T b = root ? beta : T(0);
         const std::size_t out_ld = bAc ? n_ : m_;
         const std::size_t in_ld = bAc ? m_ : n_;
-        const bool flip = pseudo_ && bAc;
-        const bool pipe = pipelined && pipeline_ && !flip && chase_hip_grid_group_active(grid_, group) != 0;
-        if (flip) {
-            flip_coltype(in + c0 * m_, nc);
-            if (b != T(0)) flip_rowtype(out + c0 * n_, nc);
-        }
+        const T* Hb = bAc ? dHbac_ : dH_;
+        const std::size_t ldb = bAc ? ldhbac_ : ldh_;
+        const bool pipe = pipelined && pipeline_ && chase_hip_grid_group_active(grid_, group) != 0;
         std::size_t c = c0;
         while (c < c0 + nc) {
             const std::size_t fp = c / PANEL;                                  // fixed panel index
             const std::size_t cend = pipe ? std::min(c0 + nc, (fp + 1) * PANEL) : c0 + nc;
             const std::size_t w = cend - c;
             if (pipe) coll(chase_hip_grid_event_wait(grid_, (int)fp));         // previous step's all-reduce of my input
-            if (bAc) gemm('C', n_, w, m_, alpha, dH_, ldh_, in + c * in_ld, in_ld, b, out + c * out_ld, out_ld);
-            else     gemm('N', m_, w, n_, alpha, dH_, ldh_, in + c * in_ld, in_ld, b, out + c * out_ld, out_ld);
+            if (bAc) gemm('C', n_, w, m_, alpha, Hb, ldb, in + c * in_ld, in_ld, b, out + c * out_ld, out_ld);
+            else     gemm('N', m_, w, n_, alpha, Hb, ldb, in + c * in_ld, in_ld, b, out + c * out_ld, out_ld);
             coll(chase_hip_grid_allreduce(grid_, group, out + c * out_ld, out_ld * w * E, pipe ? 1 : 0));
             if (pipe) coll(chase_hip_grid_event_record(grid_, (int)fp));
             c = cend;
-        }
-        if (flip) {
-            flip_coltype(in + c0 * m_, nc);
-            flip_rowtype(out + c0 * n_, nc);
         }
     }
     // X <- S X on the local rows of a column-type / row-type block (global rows >= N/2 change sign)
@@ -669,6 +665,7 @@ protected:
     chase_hip_grid* grid_;
     std::size_t N_, nev_, nex_, nevex_, nc_;
     T* dH_; std::size_t ldh_;
+    const T* dHbac_ = nullptr; std::size_t ldhbac_ = 0;      // matrix of the column->row product (see hemm_ptr)
     R* ritzv_;
     ConfigT config_;
     std::vector<R> resid_, early_;

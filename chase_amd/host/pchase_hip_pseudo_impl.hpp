@@ -33,6 +33,9 @@ public:
     {
         if (N % 2) throw std::invalid_argument("pChaseHipPseudo: N must be even (2 x 2 block structure)");
         this->pseudo_ = true;
+        this->alloc((void**)&dG_, this->m_ * this->n_ * sizeof(T));       // S H_loc S, rebuilt from H_loc at every initVecs
+        this->dHbac_ = dG_; this->ldhbac_ = this->m_;
+        build_g();
         this->alloc((void**)&dFull_, N * this->nevex_ * sizeof(T));
         this->alloc((void**)&dScal_, 4096);
         std::vector<int> km(this->m_);                       // K-conjugation partner (global row) of every local row
@@ -63,11 +66,33 @@ public:
             // that ApplyKconjugate overwrites right after the filter (algorithm.inc:1012-1064): stop at the first half
             if (c0 >= this->nevex_) { std::swap(this->dV1_, this->dV2_); return; }
             if (c0 + ncols > this->nevex_) ncols = this->nevex_ - c0;
-            this->hemm_ptr(true, this->dV1_, this->dW1_, c0, ncols, T(1), T(0), false);      // W1 = H V1   (row-type)
-            this->hemm_ptr(false, this->dW1_, this->dV2_, c0, ncols, alpha, beta, false);    // V2 = alpha H W1 + beta V2
-            upload_scalar(gamma);
-            hip_ok(chase_hip_col_axpy(this->ctx_, CP, (int)m, (int)ncols, (const double*)dScal_, 0, 0, 1.0,
-                                      this->dV1_ + c0 * m, (long)m, this->dV2_ + c0 * m, (long)m), "axpy gamma");
+            this->hemm_ptr(true, this->dV1_, this->dW1_, c0, ncols, T(1), T(0), true);       // W1 = H V1   (row-type)
+            T* v1 = this->dV1_ + c0 * m;
+            T* v2 = this->dV2_ + c0 * m;
+            if (std::imag(beta) == 0.0 && std::imag(gamma) == 0.0) {
+                // beta V2 + gamma V1 is formed on the root of the row group BEFORE the product (which then accumulates with
+                // beta' = 1 there, 0 elsewhere): nothing has to wait for the all-reduce of V2, the panel pipeline keeps
+                // running across filter steps
+                if (this->mycol_ == 0) {
+                    const double br = std::real(beta), gr = std::real(gamma);
+                    if (br == 0.0) {
+                        lacpy(ncols, v1, v2);
+                        hip_ok(chase_hip_scale_rows(this->ctx_, CP, (int)m, (int)ncols, v2, (long)m, 0, gr), "scale");
+                    } else {
+                        hip_ok(chase_hip_scale_rows(this->ctx_, CP, (int)m, (int)ncols, v2, (long)m, 0, br), "scale");
+                        upload_scalar(gamma);
+                        hip_ok(chase_hip_col_axpy(this->ctx_, CP, (int)m, (int)ncols, (const double*)dScal_, 0, 0, 1.0, v1, (long)m,
+                                                  v2, (long)m), "axpy gamma");
+                    }
+                }
+                this->hemm_ptr(false, this->dW1_, this->dV2_, c0, ncols, alpha, T(1), true);  // V2 += alpha H W1
+            } else {
+                this->hemm_ptr(false, this->dW1_, this->dV2_, c0, ncols, alpha, beta, true);  // V2 = alpha H W1 + beta V2
+                this->sync_comm();
+                upload_scalar(gamma);
+                hip_ok(chase_hip_col_axpy(this->ctx_, CP, (int)m, (int)ncols, (const double*)dScal_, 0, 0, 1.0, v1, (long)m, v2,
+                                          (long)m), "axpy gamma");
+            }
             this->hemm_calls_ += 2;
         }
         std::swap(this->dV1_, this->dV2_);
@@ -176,10 +201,29 @@ public:
 protected:
     void init_vecs_hook(bool random) override
     {
+        build_g();                                                         // H_loc is caller-owned: pick up any change
         if (random) this->flip_coltype(this->dV1_, this->nc_, 0.001);      // pchase_cpu.hpp:283-300
     }
 
 private:
+    // G_loc = S H_loc S: copy H_loc, flip the local rows with global index >= N/2, then the local columns with global
+    // index >= N/2 (entries in the lower-right quadrant are flipped twice, i.e. kept)
+    void build_g()
+    {
+        const std::size_t m = this->m_, n = this->n_, half = this->N_ / 2;
+        hip_ok(chase_hip_lacpy(this->ctx_, CP, (int)m, (int)n, this->dH_, (long)this->ldh_, dG_, (long)m), "lacpy");
+        hip_ok(chase_hip_scale_rows_bc(this->ctx_, CP, (int)m, (int)n, dG_, (long)m, (long)half, this->Rr_.nb, this->nprow_,
+                                       this->myrow_, -1.0), "flip rows");
+        const long nb = this->Cc_.nb;
+        for (std::size_t l0 = 0; l0 < n; l0 += (std::size_t)nb) {               // one column block at a time
+            const std::size_t w = std::min<std::size_t>((std::size_t)nb, n - l0);
+            const long g0 = this->Cc_.global((long)l0, this->mycol_);
+            if ((std::size_t)g0 + w <= half) continue;
+            const std::size_t skip = (std::size_t)g0 >= half ? 0 : half - (std::size_t)g0;   // block straddling N/2
+            hip_ok(chase_hip_scale_rows(this->ctx_, CP, (int)m, (int)(w - skip), dG_ + (l0 + skip) * m, (long)m, 0, -1.0),
+                   "flip columns");
+        }
+    }
     void lacpy(std::size_t ncols, const T* src, T* dst)
     {
         if (ncols) hip_ok(chase_hip_lacpy(this->ctx_, CP, (int)this->m_, (int)ncols, src, (long)this->m_, dst, (long)this->m_), "lacpy");
@@ -285,6 +329,7 @@ private:
         }
     }
 
+    T* dG_ = nullptr;
     T* dFull_ = nullptr;
     void* dScal_ = nullptr;
     int* d_kmap_ = nullptr;

@@ -67,6 +67,13 @@ def test_pseudo_solve_rccl_single_rank():
     run_ranks(1, "rccl", "pseudo_solve", 0)
 
 
+def test_pseudo_rccl_forced_through_size1_communicators(monkeypatch):
+    """the panel-pipelined pseudo-Hermitian filter (events, communication stream, real ncclAllReduce calls)"""
+    monkeypatch.setenv("CHASE_HIP_RCCL_FORCE", "1")
+    run_ranks(1, "rccl", "pseudo_solve", 0)
+    run_ranks(1, "rccl", "pseudo_ops", 0)
+
+
 @pytest.mark.parametrize("nranks,typ,mb", [(4, "z", 0), (6, "d", 16), (1, "z", 0)])
 def test_distributed_symmetry_check(nranks, typ, mb):
     run_ranks(nranks, "host", "symcheck", typ, mb)
