@@ -281,6 +281,7 @@ _sig("chase_hip_solver_peek_v", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
 _sig("chase_hip_op_start", c_int, c_void_p)
 _sig("chase_hip_op_end", c_int, c_void_p)
 _sig("chase_hip_op_initvecs", c_int, c_void_p, c_int)
+_sig("chase_hip_op_reinit_columns", c_int, c_void_p, c_size_t, P(c_size_t), c_size_t)
 _sig("chase_hip_op_shift", c_int, c_void_p, c_double, c_int)
 _sig("chase_hip_op_hemm", c_int, c_void_p, c_size_t, P(c_double), P(c_double), c_size_t, c_size_t)
 _sig("chase_hip_op_qr", c_int, c_void_p, c_size_t, c_double)
@@ -358,6 +359,10 @@ class Solver:
     def Start(self): check(lib.chase_hip_op_start(self.h), "Start")
     def End(self): check(lib.chase_hip_op_end(self.h), "End")
     def initVecs(self, random): check(lib.chase_hip_op_initvecs(self.h, int(random)), "initVecs")
+
+    def ReinitColumns(self, fixednev, cols):
+        a = (c_size_t * len(cols))(*cols)
+        check(lib.chase_hip_op_reinit_columns(self.h, fixednev, a, len(cols)), "ReinitColumns")
     def Shift(self, c, isunshift=False): check(lib.chase_hip_op_shift(self.h, float(c), int(isunshift)), "Shift")
 
     def HEMM(self, block, alpha, beta, offset_left, offset_right=0):

@@ -108,6 +108,24 @@ public:
         if (!h_on_device_)
             hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)N_, (int)N_, H_, (long)ldh_, dH_, (long)ldd_h_), "upload H");
     }
+    // chase_cpu.hpp:329-349: re-randomise the given columns (offset by fixednev) of V1 from mt19937(4242) and mirror to V2
+    void ReinitColumns(std::size_t fixednev, std::size_t const* col_indices, std::size_t n_indices) override
+    {
+        if (n_indices == 0) return;
+        flush_swaps();
+        
+        std::mt19937 gen(4242);
+        std::normal_distribution<> d;
+        std::vector<T> h(N_);
+        for (std::size_t c = 0; c < n_indices; ++c) {
+            const std::size_t j = fixednev + col_indices[c];
+            if (j >= nc_) throw std::invalid_argument("ReinitColumns: column out of range");
+            for (auto& x : h) x = rnd(d, gen);
+            hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)N_, 1, h.data(), (long)N_, dV1_ + j * N_, (long)N_), "upload column");
+            hip_ok(chase_hip_lacpy(ctx_, CP, (int)N_, 1, dV1_ + j * N_, (long)N_, dV2_ + j * N_, (long)N_), "lacpy");
+        }
+    }
+
     void End() override
     {
         flush_swaps();

@@ -198,6 +198,24 @@ public:
         flush_swaps(); sync_comm();
         hip_ok(chase_hip_download_matrix(ctx_, CP, (int)m_, (int)nc_, dV1_, (long)m_, host, (long)ldv), "download V");
     }
+    // pchase_cpu.hpp:313-331: re-randomise the given columns (offset by fixednev) of the local V1 block, mirror to V2
+    void ReinitColumns(std::size_t fixednev, std::size_t const* col_indices, std::size_t n_indices) override
+    {
+        if (n_indices == 0) return;
+        flush_swaps();
+        sync_comm(); hv_valid_ = false;
+        std::mt19937 gen(4242.0 + myrow_);                      // pchase_cpu.hpp:313-331: 4242 + grid row
+        std::normal_distribution<> d;
+        std::vector<T> h(m_);
+        for (std::size_t c = 0; c < n_indices; ++c) {
+            const std::size_t j = fixednev + col_indices[c];
+            if (j >= nc_) throw std::invalid_argument("ReinitColumns: column out of range");
+            for (auto& x : h) x = rnd(d, gen);
+            hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)m_, 1, h.data(), (long)m_, dV1_ + j * m_, (long)m_), "upload column");
+            hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, 1, dV1_ + j * m_, (long)m_, dV2_ + j * m_, (long)m_), "lacpy");
+        }
+    }
+
     void End() override { flush_swaps(); sync_comm(); hip_ok(chase_hip_ctx_sync(ctx_), "sync"); }
 
     // ---- filter --------------------------------------------------------------------------------------------------------

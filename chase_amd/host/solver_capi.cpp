@@ -299,6 +299,11 @@ const char* chase_hip_solver_trace(chase_hip_solver* s)
 /* ---- the ChaseBase virtuals, one entry point each (algorithm/interface.hpp:60-433) ---------------------------- */
 int chase_hip_op_start(chase_hip_solver* s) { return guarded("Start", [&] { DISPATCH(s, k.Start()); }); }
 int chase_hip_op_end(chase_hip_solver* s) { return guarded("End", [&] { DISPATCH(s, k.End()); }); }
+int chase_hip_op_reinit_columns(chase_hip_solver* s, size_t fixednev, const size_t* col_indices, size_t n_indices)
+{
+    if (!s || (!col_indices && n_indices)) return chase_hip::set_error(CHASE_HIP_EINVAL, "ReinitColumns: NULL argument");
+    return guarded("ReinitColumns", [&] { DISPATCH(s, k.ReinitColumns(fixednev, col_indices, n_indices)); });
+}
 int chase_hip_op_initvecs(chase_hip_solver* s, int random)
 {
     return guarded("initVecs", [&] { DISPATCH(s, k.initVecs(random != 0)); });

@@ -68,6 +68,8 @@ int chase_hip_solver_peek_v(chase_hip_solver* s, chase_hip_ctx* ctx, void* host,
 int chase_hip_op_start(chase_hip_solver* s);
 int chase_hip_op_end(chase_hip_solver* s);
 int chase_hip_op_initvecs(chase_hip_solver* s, int random);
+/* optional hook ReinitColumns (algorithm/interface.hpp; chase_cpu.hpp:329-349, pchase_cpu.hpp:313-331) */
+int chase_hip_op_reinit_columns(chase_hip_solver* s, size_t fixednev, const size_t* col_indices, size_t n_indices);
 int chase_hip_op_shift(chase_hip_solver* s, double c, int isunshift);
 int chase_hip_op_hemm(chase_hip_solver* s, size_t block, const double* alpha, const double* beta, size_t offset_left,
                       size_t offset_right);

@@ -216,3 +216,25 @@ def test_device_generated_complex_n8192_full_size_properties(ctx):
     assert np.linalg.norm(V.conj().T @ V - np.eye(nev)) < 1e-10
     s.close()
     dH.free()
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_reinit_columns_hook(ctx, cplx):
+    """Optional ChaseBase hook (chase_cpu.hpp:329-349): columns fixednev + idx of V1 are refilled from mt19937(4242),
+    N(0,1), in the order given; everything else is untouched."""
+    from chase_amd.capi import Solver
+    N, nev, nex = 64, 6, 4
+    H = O.clement(N, cplx, perturb=0)
+    s = Solver(ctx, H, nev, nex)
+    s.Start(); s.initVecs(True)
+    before = s.peek_v()
+    s.ReinitColumns(2, [0, 5, 3])
+    after = s.peek_v()
+    g = O.StdNormal(4242)
+    for c in (0, 5, 3):
+        d = g.draw(2 * N if cplx else N)
+        want = d[0::2] + 1j * d[1::2] if cplx else d
+        assert np.array_equal(after[:, 2 + c], want)
+    keep = [j for j in range(nev + nex) if j not in (2, 7, 5)]
+    assert np.array_equal(after[:, keep], before[:, keep])
+    s.close()
