@@ -44,7 +44,6 @@ public:
     using R = Base<T>;
     static constexpr int CP = is_cplx<T>::value ? 1 : 0;
     static constexpr int E = CP ? 2 : 1;
-    static constexpr std::size_t PANEL = 256;        // fixed column grid of the pipelined HEMM
 
     struct Dim {                                      // 1D block-cyclic distribution of N indices over p ranks
         long N = 0, nb = 1; int p = 1, q = 0; long nloc = 0;
@@ -86,6 +85,15 @@ public:
         // staging must hold the largest block of ANY rank (rank 0 of a dimension owns the most rows)
         alloc((void**)&dStage_, (std::size_t)std::max(Rr_.count(0), Cc_.count(0)) * nc_ * sizeof(T));
         dHbac_ = dH_; ldhbac_ = ldh_;
+        // column panel of the pipelined HEMM: a panel's GEMM should fill the chip once with whole output tiles
+        // (128-row tiles x 64 / 128 columns, two workgroups on each of the 256 CUs) in both directions; the panel grid is
+        // fixed for the object's life time (the per-panel events are indexed by it)
+        {
+            const std::size_t bn = CP ? 64 : 128, slots = 512;
+            auto need = [&](std::size_t rows) { const std::size_t rt = (rows + 127) / 128; return ((slots + rt - 1) / rt) * bn; };
+            const std::size_t w = std::max(need(m_), need(n_));
+            panel_ = std::min<std::size_t>(2048, std::max<std::size_t>(256, (w + 255) / 256 * 256));
+        }
         build_diag_lists();
         build_redistribution();
     }
@@ -481,8 +489,8 @@ protected:
         const bool pipe = pipelined && pipeline_ && chase_hip_grid_group_active(grid_, group) != 0;
         std::size_t c = c0;
         while (c < c0 + nc) {
-            const std::size_t fp = c / PANEL;                                  // fixed panel index
-            const std::size_t cend = pipe ? std::min(c0 + nc, (fp + 1) * PANEL) : c0 + nc;
+            const std::size_t fp = c / panel_;                                 // fixed panel index
+            const std::size_t cend = pipe ? std::min(c0 + nc, (fp + 1) * panel_) : c0 + nc;
             const std::size_t w = cend - c;
             if (pipe) coll(chase_hip_grid_event_wait(grid_, (int)fp));         // previous step's all-reduce of my input
             if (bAc) gemm('C', n_, w, m_, alpha, Hb, ldb, in + c * in_ld, in_ld, b, out + c * out_ld, out_ld);
@@ -693,6 +701,7 @@ protected:
     Dim Rr_, Cc_;
     std::size_t m_ = 0, n_ = 0;
     std::size_t locked_ = 0, lanczosIter_ = 0, numLanczos_ = 0;
+    std::size_t panel_ = 256;
     bool next_bAc_ = true, device_rng_ = false, pipeline_ = true, pseudo_ = false, is_sym_ = true;
     bool hv_valid_ = false, resd_reuse_ = std::getenv("CHASE_HIP_RESD_REUSE") ? std::atoi(std::getenv("CHASE_HIP_RESD_REUSE")) != 0 : true;
     std::size_t hv_locked_ = 0, hv_block_ = 0;
