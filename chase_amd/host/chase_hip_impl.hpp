@@ -42,6 +42,7 @@ struct HipImplExtras {
     virtual int last_qr_variant() const = 0;     // 0 = Householder, 1/2/3 = CholQR1 / CholQR2 / shifted CholQR2
     virtual double filter_ms() const = 0;        // HIP-event time between FilterPhaseStart/End, accumulated
     virtual std::size_t hemm_calls() const = 0;
+    virtual std::size_t hemm_reused_vecs() const { return 0; }   // filter columns served from RR's cached H V (no GEMM)
     virtual void set_device_rng(bool) = 0;
     virtual void reset_counters() = 0;
     virtual void* device_V1() = 0;               // current (local) vector block, pending swaps applied
@@ -70,6 +71,7 @@ public:
         alloc((void**)&dV1_, N_ * nevex_ * sizeof(T));
         alloc((void**)&dV2_, N_ * nevex_ * sizeof(T));
         alloc((void**)&dA_, nevex_ * nevex_ * sizeof(T));
+        alloc((void**)&dScal_, 4096);
     }
     ~ChaseHip() override
     {
@@ -205,25 +207,44 @@ public:
     // true: initVecs(random) draws N(0,1) on the device like ChASEGPU; false (default): mt19937(1337) on the host,
     // bitwise the start vectors of ChASECPU (used by the parity tests)
     void set_device_rng(bool f) override { device_rng_ = f; }
-    void reset_counters() override { filter_ms_ = 0; hemm_calls_ = 0; }
+    void reset_counters() override { filter_ms_ = 0; hemm_calls_ = 0; hemm_reused_vecs_ = 0; }
     std::size_t hemm_calls() const override { return hemm_calls_; }
+    std::size_t hemm_reused_vecs() const override { return hemm_reused_vecs_; }
 
     void Shift(T c, bool = false) override
     {
-        hv_valid_ = false;
+        hv_shift_ += std::real(c);          // the cached product belongs to the unshifted matrix: (H + sI) V = H V + s V
         hip_ok(chase_hip_shift_diag(ctx_, CP, (int)N_, dH_, (long)ldd_h_, std::real(c)), "shift_diag");
     }
 
     // V2[:, c0:c0+ncols] = alpha * H * V1[:, c0:...] + beta * V2[:, ...], c0 = locked + offset_left; then V1 <-> V2
     void HEMM(std::size_t block, T alpha, T beta, std::size_t offset_left, std::size_t offset_right = 0) override
     {
-        flush_swaps(); hv_valid_ = false;
+        flush_swaps();
         const std::size_t ncols = (offset_right < block) ? block - offset_right : 0;
         if (ncols != 0) {
             const std::size_t c0 = locked_ + offset_left;
-            gemm('N', N_, ncols, N_, alpha, dH_, ldd_h_, dV1_ + c0 * N_, N_, beta, dV2_ + c0 * N_, N_);
-            ++hemm_calls_;
+            if (hv_valid_ && beta == T(0) && std::imag(alpha) == 0.0 && c0 >= hv_locked_ &&
+                c0 + ncols <= hv_locked_ + hv_block_) {
+                // first Chebyshev step on the Ritz vectors RR just produced: alpha (H + sI) V1 = alpha (HV + s V1) with the
+                // H V that RR left behind (W A) - three streaming passes over N x ncols instead of an N^2 x ncols HEMM
+                T* v1 = dV1_ + c0 * N_;
+                T* v2 = dV2_ + c0 * N_;
+                hip_ok(chase_hip_lacpy(ctx_, CP, (int)N_, (int)ncols, dHV_ + c0 * N_, (long)N_, v2, (long)N_), "lacpy");
+                if (hv_shift_ != 0.0) {
+                    const double sc[2] = {hv_shift_, 0.0};
+                    hip_ok(chase_hip_memcpy_h2d(ctx_, dScal_, sc, sizeof sc), "h2d");
+                    hip_ok(chase_hip_col_axpy(ctx_, CP, (int)N_, (int)ncols, (const double*)dScal_, 0, 0, 1.0, v1, (long)N_, v2,
+                                              (long)N_), "axpy shift");
+                }
+                hip_ok(chase_hip_scale_rows(ctx_, CP, (int)N_, (int)ncols, v2, (long)N_, 0, std::real(alpha)), "scale");
+                hemm_reused_vecs_ += ncols;
+            } else {
+                gemm('N', N_, ncols, N_, alpha, dH_, ldd_h_, dV1_ + c0 * N_, N_, beta, dV2_ + c0 * N_, N_);
+                ++hemm_calls_;
+            }
         }
+        hv_valid_ = false;
         std::swap(dV1_, dV2_);
     }
 
@@ -268,7 +289,7 @@ public:
             // (the reference recomputes H V in Resd, chase_cpu.hpp:805-818; equal up to rounding)
             if (!dHV_) alloc((void**)&dHV_, N_ * nevex_ * sizeof(T));
             gemm('N', N_, block, block, T(1), W, N_, dA_, block, T(0), dHV_ + locked_ * N_, N_);
-            hv_valid_ = true; hv_locked_ = locked_; hv_block_ = block;
+            hv_valid_ = true; hv_locked_ = locked_; hv_block_ = block; hv_shift_ = 0.0;
         }
         gemm('N', N_, block, block, T(1), Q, N_, dA_, block, T(0), W, N_);         // W = Q A
         std::swap(dV1_, dV2_);
@@ -281,13 +302,12 @@ public:
         const std::size_t sub = nevex_ - locked_;
         T* V = dV1_ + locked_ * N_;
         T* W = dV2_ + locked_ * N_;
-        if (hv_valid_ && hv_locked_ == locked_ && hv_block_ == sub) W = dHV_ + locked_ * N_;   // H V left behind by RR
+        if (hv_valid_ && hv_shift_ == 0.0 && hv_locked_ == locked_ && hv_block_ == sub) W = dHV_ + locked_ * N_;   // H V left behind by RR
         else {
             chase_hip_ctx_set_phase(ctx_, 2);
             gemm('N', N_, sub, N_, T(1), dH_, ldd_h_, V, N_, T(0), W, N_);
             chase_hip_ctx_set_phase(ctx_, 0);
         }
-        hv_valid_ = false;
         hip_ok(chase_hip_resid_norms(ctx_, CP, (int)N_, (int)sub, W, (long)N_, V, (long)N_, ritzv, resd, 0), "resid");
         if (resd != resid_.data() + locked_) std::memcpy(resid_.data() + locked_, resd, sub * sizeof(R));
     }
@@ -368,13 +388,16 @@ private:
     void flush_swaps()
     {
         if (!perm_dirty_) return;
-        hv_valid_ = false;
         std::vector<int> src, dst;
         for (std::size_t j = 0; j < nevex_; ++j)
             if (perm_[j] != (int)j) { src.push_back(perm_[j]); dst.push_back((int)j); }
-        if (!src.empty())
+        if (!src.empty()) {
             hip_ok(chase_hip_permute_cols(ctx_, CP, (int)N_, dV1_, (long)N_, dV2_, (long)N_, src.data(), dst.data(),
                                           (int)src.size()), "permute_cols");
+            if (hv_valid_)       // the cached H V follows its vectors
+                hip_ok(chase_hip_permute_cols(ctx_, CP, (int)N_, dHV_, (long)N_, dV2_, (long)N_, src.data(), dst.data(),
+                                              (int)src.size()), "permute_cols");
+        }
         reset_perm();
     }
 
@@ -458,7 +481,9 @@ private:
     T *dH_ = nullptr, *dV1_ = nullptr, *dV2_ = nullptr, *dA_ = nullptr, *dHV_ = nullptr;
     std::size_t ldd_h_ = 0;
     bool hv_valid_ = false, resd_reuse_ = std::getenv("CHASE_HIP_RESD_REUSE") ? std::atoi(std::getenv("CHASE_HIP_RESD_REUSE")) != 0 : true;
-    std::size_t hv_locked_ = 0, hv_block_ = 0;
+    std::size_t hv_locked_ = 0, hv_block_ = 0, hemm_reused_vecs_ = 0;
+    double hv_shift_ = 0.0;
+    void* dScal_ = nullptr;
     std::vector<void*> owned_;
     double filter_ms_ = 0;
     std::size_t hemm_calls_ = 0;

@@ -164,8 +164,9 @@ public:
     int last_qr_variant() const override { return last_qr_variant_; }
     double filter_ms() const override { return filter_ms_; }
     std::size_t hemm_calls() const override { return hemm_calls_; }
+    std::size_t hemm_reused_vecs() const override { return hemm_reused_vecs_; }
     void set_device_rng(bool f) override { device_rng_ = f; }
-    void reset_counters() override { filter_ms_ = 0; hemm_calls_ = 0; }
+    void reset_counters() override { filter_ms_ = 0; hemm_calls_ = 0; hemm_reused_vecs_ = 0; }
     void* device_V1() override { flush_swaps(); sync_comm(); return dV1_; }
     std::size_t local_rows() const override { return m_; }
     std::size_t local_cols_h() const { return n_; }
@@ -245,7 +246,7 @@ public:
     // mpi/shiftDiagonal.hpp:21-78 / cuda/shiftDiagonal.cu:100-149: shift the locally owned diagonal entries
     void Shift(T c, bool isunshift = false) override
     {
-        hv_valid_ = false;
+        hv_shift_ += std::real(c);          // the cached products belong to the unshifted matrix: (H + sI) V = H V + s V
         if (isunshift) next_bAc_ = true;
         hip_ok(chase_hip_shift_list(ctx_, CP, dH_, (long)ldh_, d_diag_rows_, d_diag_cols_, (int)diag_cnt_, std::real(c)),
                "shift_list");
@@ -253,12 +254,31 @@ public:
 
     void HEMM(std::size_t block, T alpha, T beta, std::size_t offset_left, std::size_t offset_right = 0) override
     {
-        flush_swaps(); hv_valid_ = false;
+        flush_swaps();
         const std::size_t ncols = (offset_right < block) ? block - offset_right : 0;
         if (ncols != 0) {
-            hemm_dir(next_bAc_, locked_ + offset_left, ncols, alpha, beta, true);
-            ++hemm_calls_;
+            const std::size_t c0 = locked_ + offset_left;
+            if (hv_valid_ && next_bAc_ && beta == T(0) && std::imag(alpha) == 0.0 && c0 >= hv_locked_ &&
+                c0 + ncols <= hv_locked_ + hv_block_) {
+                // first Chebyshev step on the Ritz vectors RR just produced: the row-type result alpha (H + sI) V is formed
+                // from the row-type H V (dW3_) and V (dW1_) that RR left behind - no GEMM, no all-reduce
+                T* w1 = dW1_ + c0 * n_;
+                if (hv_shift_ != 0.0)
+                    hip_ok(chase_hip_scale_rows(ctx_, CP, (int)n_, (int)ncols, w1, (long)n_, 0, hv_shift_), "scale");
+                else
+                    hip_ok(chase_hip_memset(ctx_, w1, 0, n_ * ncols * sizeof(T)), "memset");
+                const double one[2] = {1.0, 0.0};
+                hip_ok(chase_hip_memcpy_h2d(ctx_, dPack_, one, sizeof one), "h2d");
+                hip_ok(chase_hip_col_axpy(ctx_, CP, (int)n_, (int)ncols, (const double*)dPack_, 0, 0, 1.0, dW3_ + c0 * n_, (long)n_,
+                                          w1, (long)n_), "axpy");
+                hip_ok(chase_hip_scale_rows(ctx_, CP, (int)n_, (int)ncols, w1, (long)n_, 0, std::real(alpha)), "scale");
+                hemm_reused_vecs_ += ncols;
+            } else {
+                hemm_dir(next_bAc_, c0, ncols, alpha, beta, true);
+                ++hemm_calls_;
+            }
         }
+        hv_valid_ = false;
         next_bAc_ = !next_bAc_;
     }
 
@@ -308,7 +328,7 @@ public:
             if (!dW3_) alloc((void**)&dW3_, n_ * nc_ * sizeof(T));
             gemm('N', n_, block, block, T(1), dW1_ + c0 * n_, n_, dA_, block, T(0), dW3_ + c0 * n_, n_);
             gemm('N', n_, block, block, T(1), dW2_ + c0 * n_, n_, dA_, block, T(0), dW1_ + c0 * n_, n_);
-            hv_valid_ = true; hv_locked_ = locked_; hv_block_ = block;
+            hv_valid_ = true; hv_locked_ = locked_; hv_block_ = block; hv_shift_ = 0.0;
         }
         gemm('N', m_, block, block, T(1), dV2_ + c0 * m_, m_, dA_, block, T(0), dV1_ + c0 * m_, m_);
         hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)block, dV1_ + c0 * m_, (long)m_, dV2_ + c0 * m_, (long)m_), "lacpy");
@@ -320,7 +340,7 @@ public:
         flush_swaps(); sync_comm();
         const std::size_t c0 = locked_, sub = nevex_ - locked_;
         const T *HV, *Vr;
-        if (hv_valid_ && hv_locked_ == locked_ && hv_block_ == sub) {        // left behind by RR
+        if (hv_valid_ && hv_shift_ == 0.0 && hv_locked_ == locked_ && hv_block_ == sub) {   // left behind by RR
             HV = dW3_ + c0 * n_; Vr = dW1_ + c0 * n_;
         } else {
             chase_hip_ctx_set_phase(ctx_, 2);
@@ -328,8 +348,8 @@ public:
             chase_hip_ctx_set_phase(ctx_, 0);
             redistribute_c2r(dV2_ + c0 * m_, dW2_ + c0 * n_, sub);           // W2 = V2 (== V1) row-type
             HV = dW1_ + c0 * n_; Vr = dW2_ + c0 * n_;
+            hv_valid_ = false;                                               // dW1_ no longer holds the cached V
         }
-        hv_valid_ = false;
         hip_ok(chase_hip_resid_norms(ctx_, CP, (int)n_, (int)sub, HV, (long)n_, Vr, (long)n_,
                                      ritzv, resd, 1), "resid_norms");      // local sums of squares
         // all-reduce over the row communicator, then sqrt (mpi/residuals.hpp:99-105)
@@ -587,7 +607,6 @@ protected:
     void flush_swaps()
     {
         if (!perm_dirty_) return;
-        hv_valid_ = false;
         sync_comm();
         std::vector<int> src, dst;
         for (std::size_t j = 0; j < nc_; ++j)
@@ -595,6 +614,10 @@ protected:
         if (!src.empty()) {
             hip_ok(chase_hip_permute_cols(ctx_, CP, (int)m_, dV1_, (long)m_, dVt_, (long)m_, src.data(), dst.data(), (int)src.size()), "permute");
             hip_ok(chase_hip_permute_cols(ctx_, CP, (int)m_, dV2_, (long)m_, dVt_, (long)m_, src.data(), dst.data(), (int)src.size()), "permute");
+            if (hv_valid_) {     // the cached row-type H V and V follow their vectors (dW2_ is free scratch after RR)
+                hip_ok(chase_hip_permute_cols(ctx_, CP, (int)n_, dW3_, (long)n_, dW2_, (long)n_, src.data(), dst.data(), (int)src.size()), "permute");
+                hip_ok(chase_hip_permute_cols(ctx_, CP, (int)n_, dW1_, (long)n_, dW2_, (long)n_, src.data(), dst.data(), (int)src.size()), "permute");
+            }
         }
         reset_perm();
     }
@@ -704,7 +727,8 @@ protected:
     std::size_t panel_ = 256;
     bool next_bAc_ = true, device_rng_ = false, pipeline_ = true, pseudo_ = false, is_sym_ = true;
     bool hv_valid_ = false, resd_reuse_ = std::getenv("CHASE_HIP_RESD_REUSE") ? std::atoi(std::getenv("CHASE_HIP_RESD_REUSE")) != 0 : true;
-    std::size_t hv_locked_ = 0, hv_block_ = 0;
+    std::size_t hv_locked_ = 0, hv_block_ = 0, hemm_reused_vecs_ = 0;
+    double hv_shift_ = 0.0;
     T* dW3_ = nullptr;
     T *dV1_ = nullptr, *dV2_ = nullptr, *dVt_ = nullptr, *dW1_ = nullptr, *dW2_ = nullptr, *dA_ = nullptr;
     T *dPack_ = nullptr, *dStage_ = nullptr;

@@ -223,6 +223,7 @@ int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* out)
         else if (name == "qr_variant") *out = (double)s->ex->last_qr_variant();
         else if (name == "filter_ms") *out = s->ex->filter_ms();
         else if (name == "hemm_calls") *out = (double)s->ex->hemm_calls();
+        else if (name == "hemm_reused_vecs") *out = (double)s->ex->hemm_reused_vecs();
         else rc = chase_hip::set_error(CHASE_HIP_EINVAL, "solver_get: unknown key");
     });
     return rc;
