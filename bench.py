@@ -30,9 +30,12 @@ MATRIX_SCALE = 100.0
 MATRIX_PERTURB = 1e-6
 
 DEFAULT_WORKLOAD = "cfg2"
-# BASELINE.json assigns one configuration to each GPU count (configs[1] 1 GPU, configs[2] 4 GPUs, configs[3] 8 GPUs);
-# 2 GPUs run configs[2] on a 2x1 grid.  --workload overrides (e.g. cfg4 on every N for a strong-scaling series).
-DEFAULT_BY_GPUS = {1: "cfg2", 2: "cfg3", 4: "cfg3", 8: "cfg4"}
+# BASELINE.json assigns one configuration to each GPU count (configs[1] 1 GPU, configs[2] 4 GPUs, configs[3] 8 GPUs).
+# The default series keeps ONE arithmetic type (complex Hermitian, like the 1- and 8-GPU configurations) so that the
+# per-N values are comparable: 2 and 4 GPUs run the complex twin of configs[2] (same N, nev, nex; "cfg3c") on 2x1 / 2x2
+# grids; the real-symmetric configs[2] itself is --workload cfg3.  --workload overrides (e.g. cfg4 on every N for a
+# strong-scaling series).
+DEFAULT_BY_GPUS = {1: "cfg2", 2: "cfg3c", 4: "cfg3c", 8: "cfg4"}
 DEFAULT_BLOCK_CYCLIC = {"cfg4": 64}          # BASELINE configs[3]: block-cyclic distribution (nb = 64, examples/1_hello_world)
 
 WORKLOADS = {
@@ -40,6 +43,7 @@ WORKLOADS = {
     "cfg1": (4096, False, 100, 40),
     "cfg2": (16384, True, 512, 128),
     "cfg3": (32768, False, 1024, 256),
+    "cfg3c": (32768, True, 1024, 256),
     "cfg4": (65536, True, 2048, 512),
     # BASELINE configs[4]: pseudo-Hermitian Bethe-Salpeter, chase::Solve_pseudo, nex = nev/4 like the other configurations;
     # synthetic matrix chase_hip_gen_bse (dmin 1, dmax 11, off-diagonal 1e-3 N(0,1)); always runs the grid Impl
