@@ -82,3 +82,12 @@ def test_distributed_symmetry_check(nranks, typ, mb):
 @pytest.mark.parametrize("nranks,typ", [(4, "z"), (2, "d")])
 def test_distributed_qr_on_reference_fixtures(nranks, typ):
     run_ranks(nranks, "host", "qr_fixtures", typ)
+
+
+def test_solve_blockcyclic_4x2_eight_ranks():
+    """the 8-GPU grid shape of BASELINE configs[3] (4 x 2, block-cyclic nb = 64), eight ranks sharing one GPU"""
+    run_ranks(8, "host", "solve", 1024, 100, 60, "z", 64, 20, timeout=900)
+
+
+def test_pseudo_solve_4x2_eight_ranks():
+    run_ranks(8, "host", "pseudo_solve", 0, timeout=900)
