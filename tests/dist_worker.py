@@ -238,6 +238,26 @@ def scenario_qr_fixtures(ctx, grid, rank, world, cplx):
     v, o = run("cond_1e4.bin", 1e4, cholqr=0); assert v == 0 and o <= 25 * EPS              # Householder requested
 
 
+def scenario_reference_run_counts(ctx, grid, rank, world):
+    """The reference's own example run, measured with the actual reference binary (BASELINE.md "Cross-check measured with
+    the actual reference"): examples/1_hello_world, pChASECPU, unperturbed complex Clement N = 1200, nev = 80, nex = 60,
+    block-cyclic nb = 64 on a 2 x 2 grid, start vectors mt19937(1337 + grid row) -> 6 iterations, 13 310 filtered vectors,
+    eigenvalues -N, -N+2, ..."""
+    assert (grid.nprow, grid.npcol) == (2, 2)
+    N, nev, nex, nb = 1200, 80, 60, 64
+    H = O.clement(N, True, perturb=0)
+    rl, cl = cd.Layout(N, nb, grid.nprow), cd.Layout(N, nb, grid.npcol)
+    dH = ctx.array(cd.local_block_of(H, rl, cl, grid.myrow, grid.mycol))
+    s = cd.DistSolver(ctx, grid, dH, N, nev, nex, True, nb, nb)
+    s.set(deg=20, opt=1, tol=1e-10)                       # host RNG (the reference's generator), not the device Philox
+    st = s.solve()
+    note(f"iterations {st['iterations']} filtered {st['filtered_vecs']}")
+    assert st["iterations"] == 6 and st["filtered_vecs"] == 13310, (st["iterations"], st["filtered_vecs"])
+    assert np.max(np.abs(s.ritzv[:nev] - (-N + 2.0 * np.arange(nev)))) < 1e-8
+    assert np.max(s.resid()[:nev]) <= 1e-10
+    s.close()
+
+
 def bse_fixture():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import conftest
@@ -354,6 +374,8 @@ def main():
         elif scen == "solve":
             N, nev, nex = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
             scenario_solve(ctx, grid, rank, world, N, nev, nex, sys.argv[6] == "z", int(sys.argv[7]), int(sys.argv[8]))
+        elif scen == "refcounts":
+            scenario_reference_run_counts(ctx, grid, rank, world)
         elif scen == "qr_fixtures":
             scenario_qr_fixtures(ctx, grid, rank, world, sys.argv[3] == "z")
         elif scen == "symcheck":

@@ -91,3 +91,9 @@ def test_solve_blockcyclic_4x2_eight_ranks():
 
 def test_pseudo_solve_4x2_eight_ranks():
     run_ranks(8, "host", "pseudo_solve", 0, timeout=900)
+
+
+def test_distributed_run_reproduces_the_reference_example_run():
+    """examples/1_hello_world measured with the actual reference (pChASECPU, 2 x 2, block-cyclic nb = 64): 6 iterations,
+    13 310 filtered vectors (BASELINE.md cross-check table)"""
+    run_ranks(4, "host", "refcounts")

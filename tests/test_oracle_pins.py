@@ -186,3 +186,16 @@ def test_lanczos_for_H2_reference_assertions():
     k.QR(0, 1.0)
     upperb, idx = O.lanczos_for_H2(k, n, numvec, m, nev + nex, k.ritzv)
     _lanczos_for_H2_reference_assertions(eigs, nev + nex, m, upperb, idx, k.ritzv)
+
+
+@pytest.mark.parametrize("N,cplx,nev,nex,iters,vecs", [(4096, False, 100, 40, 8, 24988), (1200, True, 80, 60, 5, 12664)])
+def test_oracle_reproduces_runs_of_the_actual_reference(N, cplx, nev, nex, iters, vecs):
+    """Outputs of the reference binary itself (BASELINE.md "Cross-check measured with the actual reference"):
+    ChASECPU<double> on the unperturbed Clement matrix N = 4096, nev = 100, nex = 40 -> 8 iterations, 24 988 filtered vectors;
+    tests/noinput.cpp problem #0 (ChASECPU<complex<double>>, N = 1200, nev = 80, nex = 60) -> 5 iterations, 12 664 vectors;
+    eigenvalues -N, -N+2, ..., residuals below 1e-10.  Defaults: tol 1e-10, deg 20, opt on, mt19937(1337) start block."""
+    k = O.OracleCPU(O.clement(N, cplx, perturb=0), nev, nex)
+    so = O.solve(k)
+    assert (so["iterations"], so["filtered_vecs"]) == (iters, vecs)
+    assert np.max(np.abs(k.ritzv[:nev] - (-N + 2.0 * np.arange(nev)))) < 1e-8
+    assert np.max(k.resid[:nev]) <= 1e-10
