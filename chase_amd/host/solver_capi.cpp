@@ -194,6 +194,8 @@ int chase_hip_solver_set(chase_hip_solver* s, const char* key, double v)
         else if (name == "approx") c.SetApprox(v != 0);
         else if (name == "cholqr") c.SetCholQR(v != 0);
         else if (name == "decayingrate") c.SetDecayingRate((float)v);
+        else if (name == "clusteraware") c.SetClusterAwareDegrees(v != 0);
+        else if (name == "upperbscale") c.SetUpperbScaleRate((float)v);
         else if (name == "device_rng") s->ex->set_device_rng(v != 0);
         else if (name == "reset_counters") s->ex->reset_counters();
         else rc = chase_hip::set_error(CHASE_HIP_EINVAL, "solver_set: unknown key");
@@ -219,6 +221,8 @@ int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* out)
         else if (name == "approx") *out = c.UseApprox();
         else if (name == "cholqr") *out = c.DoCholQR();
         else if (name == "decayingrate") *out = c.GetDecayingRate();
+        else if (name == "clusteraware") *out = c.UseClusterAwareDegrees();
+        else if (name == "upperbscale") *out = c.GetUpperbScaleRate();
         else if (name == "locked") *out = (double)s->ex->locked();
         else if (name == "qr_variant") *out = (double)s->ex->last_qr_variant();
         else if (name == "filter_ms") *out = s->ex->filter_ms();
