@@ -1,13 +1,35 @@
-// c_interface.cpp — ChASE's application-facing C interface (interface/chase_c_interface.h:13-41) on top of the HIP Impl.
+// c_interface.cpp — ChASE's application-facing C interface (interface/chase_c_interface.h:13-58,177-181; sequential fp64
+// entry points) on top of the HIP Impl.  Behaviour follows interface/chase_c_interface.cpp: one solver object per type
+// kept between init / solve / finalize; zchase_ dispatches to the pseudo-Hermitian solver when that is the one that was
+// initialised (chase_c_interface.cpp:2204-2220); the *_internal_ inits own the vector / Ritz-value storage and
+// ?chase_get_eigenpairs_ copies the first nev eigenvectors and Ritz values out (chase_c_interface.cpp:2329-2400).
+#include <complex>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 #include "../../include/chase_c_interface.h"
 #include "../../include/chase_hip.h"
 #include "../../include/chase_hip_solver.h"
 
 namespace {
 chase_hip_ctx* g_ctx = nullptr;
-chase_hip_solver* g_d = nullptr;
-chase_hip_solver* g_z = nullptr;
+
+struct Slot {
+    chase_hip_solver* s = nullptr;
+    int cplx = 0, pseudo = 0;
+    std::size_t N = 0, nev = 0, nex = 0;
+    void* V = nullptr;                       // vector block the solver works on (caller's or internal)
+    double* ritzv = nullptr;
+    std::vector<double> own_v, own_ritzv;    // storage of the *_internal_ variants
+    void clear()
+    {
+        if (s) { chase_hip_solver_destroy(s); s = nullptr; }
+        own_v.clear(); own_v.shrink_to_fit(); own_ritzv.clear();
+        V = nullptr; ritzv = nullptr;
+    }
+};
+Slot g_d, g_z, g_zp;
+int g_sym_check = 1;
 
 bool ensure_ctx()
 {
@@ -16,47 +38,99 @@ bool ensure_ctx()
     if (const char* e = std::getenv("CHASE_HIP_DEVICE")) dev = std::atoi(e);
     return chase_hip_ctx_create(&g_ctx, dev, nullptr) == 0;
 }
-void init_common(chase_hip_solver** slot, int cplx, int N, int nev, int nex, void* H, int ldh, void* V, double* ritzv,
-                 int* init)
+void init_common(Slot& sl, int cplx, int pseudo, int N, int nev, int nex, void* H, int ldh, void* V, double* ritzv, int* init)
 {
     *init = 0;
     if (!ensure_ctx()) return;
-    if (*slot) { chase_hip_solver_destroy(*slot); *slot = nullptr; }
-    if (chase_hip_solver_create(slot, g_ctx, cplx, (size_t)N, (size_t)nev, (size_t)nex, H, (size_t)ldh, V, (size_t)N,
-                                ritzv, 0) == 0)
-        *init = 1;
+    if (sl.s) { chase_hip_solver_destroy(sl.s); sl.s = nullptr; }
+    const std::size_t ncol = (pseudo ? 2 : 1) * (std::size_t)(nev + nex);
+    if (!V) {                                 // *_internal_: the interface owns V and ritzv
+        sl.own_v.assign((std::size_t)N * ncol * (cplx ? 2 : 1), 0.0);
+        sl.own_ritzv.assign(ncol, 0.0);
+        V = sl.own_v.data(); ritzv = sl.own_ritzv.data();
+    }
+    sl.cplx = cplx; sl.pseudo = pseudo; sl.N = (std::size_t)N; sl.nev = (std::size_t)nev; sl.nex = (std::size_t)nex;
+    sl.V = V; sl.ritzv = ritzv;
+    const int rc = pseudo ? chase_hip_solver_create_pseudo(&sl.s, g_ctx, cplx, (size_t)N, (size_t)nev, (size_t)nex, H,
+                                                           (size_t)ldh, V, (size_t)N, ritzv, 0)
+                          : chase_hip_solver_create(&sl.s, g_ctx, cplx, (size_t)N, (size_t)nev, (size_t)nex, H, (size_t)ldh,
+                                                    V, (size_t)N, ritzv, 0);
+    if (rc == 0) *init = 1;
 }
-void solve_common(chase_hip_solver* s, int deg, double tol, char mode, char opt, char qr)
+void solve_common(Slot& sl, int deg, double tol, char mode, char opt, char qr)
 {
-    if (!s) return;
-    chase_hip_solver_set(s, "tol", tol);
-    chase_hip_solver_set(s, "deg", (double)deg);
-    chase_hip_solver_set(s, "opt", opt == 'S' ? 1.0 : 0.0);
-    chase_hip_solver_set(s, "approx", mode == 'A' ? 1.0 : 0.0);
-    chase_hip_solver_set(s, "cholqr", qr == 'C' ? 1.0 : 0.0);
-    chase_hip_solver_solve(s, 0);
+    if (!sl.s) return;
+    chase_hip_solver_set(sl.s, "tol", tol);
+    chase_hip_solver_set(sl.s, "deg", (double)deg);
+    chase_hip_solver_set(sl.s, "opt", opt == 'S' ? 1.0 : 0.0);
+    chase_hip_solver_set(sl.s, "approx", mode == 'A' ? 1.0 : 0.0);
+    chase_hip_solver_set(sl.s, "cholqr", qr == 'C' ? 1.0 : 0.0);
+    chase_hip_solver_solve(sl.s, 0);
+}
+// first nev eigenvectors (N x nev, leading dimension ld) and Ritz values
+void get_pairs(const Slot& sl, void* out, int ld, double* ritzv)
+{
+    if (!sl.s || !sl.V || !out || ld < (int)sl.N) return;
+    const std::size_t es = sl.cplx ? 16 : 8;
+    for (std::size_t j = 0; j < sl.nev; ++j)
+        std::memcpy((char*)out + j * (std::size_t)ld * es, (const char*)sl.V + j * sl.N * es, sl.N * es);
+    if (ritzv) std::memcpy(ritzv, sl.ritzv, sl.nev * sizeof(double));
 }
 } // namespace
 
 extern "C" {
 void dchase_init_(int* N, int* nev, int* nex, double* H, int* ldh, double* V, double* ritzv, int* init)
 {
-    init_common(&g_d, 0, *N, *nev, *nex, H, *ldh, V, ritzv, init);
+    init_common(g_d, 0, 0, *N, *nev, *nex, H, *ldh, V, ritzv, init);
+}
+void dchase_init_internal_(int* N, int* nev, int* nex, double* H, int* ldh, int* init)
+{
+    init_common(g_d, 0, 0, *N, *nev, *nex, H, *ldh, nullptr, nullptr, init);
 }
 void dchase_(int* deg, double* tol, char* mode, char* opt, char* qr) { solve_common(g_d, *deg, *tol, *mode, *opt, *qr); }
+void dchase_get_eigenpairs_(double* LEigsV, int* ld, double* ritzv) { if (ld) get_pairs(g_d, LEigsV, *ld, ritzv); }
 void dchase_finalize_(int* flag)
 {
-    if (g_d) { chase_hip_solver_destroy(g_d); g_d = nullptr; }
+    g_d.clear();
     *flag = 1;
 }
+
 void zchase_init_(int* N, int* nev, int* nex, void* H, int* ldh, void* V, double* ritzv, int* init)
 {
-    init_common(&g_z, 1, *N, *nev, *nex, H, *ldh, V, ritzv, init);
+    g_zp.clear();
+    init_common(g_z, 1, 0, *N, *nev, *nex, H, *ldh, V, ritzv, init);
 }
-void zchase_(int* deg, double* tol, char* mode, char* opt, char* qr) { solve_common(g_z, *deg, *tol, *mode, *opt, *qr); }
+void zchase_init_internal_(int* N, int* nev, int* nex, void* H, int* ldh, int* init)
+{
+    g_zp.clear();
+    init_common(g_z, 1, 0, *N, *nev, *nex, H, *ldh, nullptr, nullptr, init);
+}
+void zchase_init_pseudo_(int* N, int* nev, int* nex, void* H, int* ldh, void* V, double* ritzv, int* init)
+{
+    g_z.clear();
+    init_common(g_zp, 1, 1, *N, *nev, *nex, H, *ldh, V, ritzv, init);
+}
+void zchase_init_pseudo_internal_(int* N, int* nev, int* nex, void* H, int* ldh, int* init)
+{
+    g_z.clear();
+    init_common(g_zp, 1, 1, *N, *nev, *nex, H, *ldh, nullptr, nullptr, init);
+}
+void zchase_pseudo_(int* deg, double* tol, char* mode, char* opt, char* qr) { solve_common(g_zp, *deg, *tol, *mode, *opt, *qr); }
+void zchase_(int* deg, double* tol, char* mode, char* opt, char* qr)
+{
+    if (g_zp.s) solve_common(g_zp, *deg, *tol, *mode, *opt, *qr);       // the type that was initialised decides
+    else solve_common(g_z, *deg, *tol, *mode, *opt, *qr);
+}
+void zchase_get_eigenpairs_(void* LEigsV, int* ld, double* ritzv)
+{
+    if (!ld) return;
+    if (g_zp.s) get_pairs(g_zp, LEigsV, *ld, ritzv);
+    else get_pairs(g_z, LEigsV, *ld, ritzv);
+}
 void zchase_finalize_(int* flag)
 {
-    if (g_z) { chase_hip_solver_destroy(g_z); g_z = nullptr; }
+    g_z.clear(); g_zp.clear();
     *flag = 1;
 }
+void chase_enable_sym_check_(int* flag) { if (flag) g_sym_check = *flag != 0; }
 }

@@ -251,3 +251,57 @@ def test_hip_path_reproduces_runs_of_the_actual_reference(ctx, N, cplx, nev, nex
     assert np.max(np.abs(s.ritzv[:nev] - (-N + 2.0 * np.arange(nev)))) < 1e-8
     assert np.max(s.resid()[:nev]) <= 1e-10
     s.close()
+
+
+def test_c_interface_internal_storage_and_get_eigenpairs(ctx):
+    """dchase_init_internal_ + dchase_ + dchase_get_eigenpairs_ (interface/chase_c_interface.h:25,38,177): the interface
+    owns V / ritzv, the caller reads the first nev pairs out."""
+    import ctypes as C
+    from chase_amd.capi import lib
+    N, nev, nex = 200, 12, 8
+    H = O.clement(N, False)
+    ci = lambda v: C.byref(C.c_int(v))
+    init = C.c_int(0)
+    lib.dchase_init_internal_(ci(N), ci(nev), ci(nex), C.c_void_p(H.ctypes.data), ci(N), C.byref(init))
+    assert init.value == 1
+    lib.dchase_(ci(16), C.byref(C.c_double(1e-10)), C.c_char_p(b"R"), C.c_char_p(b"S"), C.c_char_p(b"C"))
+    ld = N + 3
+    V = np.zeros((ld, nev), order="F")
+    lam = np.zeros(nev)
+    lib.dchase_get_eigenpairs_(C.c_void_p(V.ctypes.data), ci(ld), C.c_void_p(lam.ctypes.data))
+    assert np.max(O.residuals(H, lam, V[:N, :])) < RESID_TOL and np.all(V[N:, :] == 0)
+    flag = C.c_int(0)
+    lib.dchase_finalize_(C.byref(flag))
+    assert flag.value == 1
+
+
+def test_c_interface_pseudo_hermitian(ctx):
+    """zchase_init_pseudo_ + zchase_ (dispatches to the pseudo solver, chase_c_interface.cpp:2204-2220) + zchase_pseudo_ +
+    zchase_get_eigenpairs_ on the reference's BSE fixture."""
+    import ctypes as C
+    import os
+    from conftest import REF_FIX, read_ref_matrix
+    from chase_amd.capi import lib
+    N, nev, nex = 200, 20, 20
+    H = read_ref_matrix("cdouble_random_BSE.bin", N, N, True)
+    eigs = np.fromfile(os.path.join(REF_FIX, "eigs_cdouble_random_BSE.bin"), dtype=np.complex128).real
+    pos = np.sort(eigs[eigs > 0])
+    V = np.zeros((N, 2 * (nev + nex)), dtype=np.complex128, order="F")
+    lam = np.zeros(2 * (nev + nex))
+    ci = lambda v: C.byref(C.c_int(v))
+    init = C.c_int(0)
+    lib.zchase_init_pseudo_(ci(N), ci(nev), ci(nex), C.c_void_p(H.ctypes.data), ci(N), C.c_void_p(V.ctypes.data),
+                            C.c_void_p(lam.ctypes.data), C.byref(init))
+    assert init.value == 1
+    for fn in (lib.zchase_, lib.zchase_pseudo_):
+        V[:] = 0; lam[:] = 0
+        fn(ci(20), C.byref(C.c_double(1e-10)), C.c_char_p(b"R"), C.c_char_p(b"S"), C.c_char_p(b"C"))
+        assert np.max(np.abs(lam[:nev] - pos[:nev])) <= 1e-9
+        assert np.max(np.linalg.norm(H @ V[:, :nev] - V[:, :nev] * lam[None, :nev], axis=0)) <= 1e-9
+    out = np.zeros((N, nev), dtype=np.complex128, order="F")
+    lo = np.zeros(nev)
+    lib.zchase_get_eigenpairs_(C.c_void_p(out.ctypes.data), ci(N), C.c_void_p(lo.ctypes.data))
+    assert np.array_equal(out, V[:, :nev]) and np.array_equal(lo, lam[:nev])
+    flag = C.c_int(0)
+    lib.zchase_finalize_(C.byref(flag))
+    assert flag.value == 1
