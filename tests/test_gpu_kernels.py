@@ -358,3 +358,4 @@ def test_conj_inplace(ctx):
     d = ctx.array(X)
     check(lib.chase_hip_conj(ctx.h, 33, 5, d.ptr, 33), "conj")
     assert np.array_equal(d.download(), X.conj())
+
