@@ -30,7 +30,25 @@ def run_distributed(args):
     ctx = Context(local_rank % max(ndev, 1))
     pg = cd.make_process_groups(nprow, npcol)
     transport = os.environ.get("CHASE_HIP_TRANSPORT", "rccl")
-    grid = cd.Grid(ctx, nprow, npcol, rank, transport=transport, pg=pg)
+    grid, err = None, ""
+    try:
+        grid = cd.Grid(ctx, nprow, npcol, rank, transport=transport, pg=pg)
+    except Exception as e:  # communicator creation failed on this rank
+        err = str(e)
+    # every rank must take the same transport: agree on success, fall back together (numbers measured through the host
+    # transport are labelled as such in config.workload - they are a functional fallback, not the RCCL path)
+    okflag = torch.tensor([1 if grid is not None else 0], dtype=torch.int32)
+    dist.all_reduce(okflag, op=dist.ReduceOp.MIN)
+    if int(okflag[0]) == 0:
+        if grid is not None:
+            grid.close()
+        if transport != "rccl":
+            raise RuntimeError("grid creation failed: " + err)
+        if rank == 0:
+            import sys
+            print("bench: RCCL grid creation failed (%s); falling back to the host-callback transport" % err, file=sys.stderr)
+        transport = "host"
+        grid = cd.Grid(ctx, nprow, npcol, rank, transport=transport, pg=pg)
     # RCCL prints a version banner through C stdio at communicator creation; push it out NOW on every rank so that the
     # JSON line rank 0 prints at the end is the last line of the job's stdout
     import ctypes
