@@ -573,19 +573,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
 }
 
 // tail tiles: C[tile] = alpha * sum_z slab[tile][z] + beta * C[tile]   (fixed summation order => bitwise reproducible)
-// one workgroup per tail tile; slabs are BM x BN tiles (ld = BM) in tile-local coordinates
+// TAIL_PARTS workgroups per tail tile (each sums its share of the tile's elements over the sk slabs in slab order);
+// slabs are BM x BN tiles (ld = BM) in tile-local coordinates
+constexpr int TAIL_PARTS = 4;
 template <bool CPLX, int BM, int BN>
 __global__ __launch_bounds__(256) void tail_reduce_kernel(const double* __restrict__ slabs, int first_tile, int sk,
                                                           int gn, int m, int n, double* __restrict__ C, long ldc,
                                                           double are, double aim, double bre, double bim)
 {
     constexpr int EPT = CPLX ? 2 : 1;
-    const int tt = blockIdx.x;
+    const int tt = blockIdx.x / TAIL_PARTS, part = blockIdx.x % TAIL_PARTS;
     const int tile = first_tile + tt;
     const int row0 = (tile / gn) * BM, col0 = (tile % gn) * BN;
     const double* base = slabs + (size_t)tt * sk * (BM * BN * EPT);
     const bool has_beta = (bre != 0.0) || (bim != 0.0);
-    for (int e = threadIdx.x; e < BM * BN; e += 256) {
+    constexpr int SHARE = BM * BN / TAIL_PARTS;
+    for (int e = part * SHARE + threadIdx.x; e < (part + 1) * SHARE; e += 256) {
         const int li = e % BM, lj = e / BM;
         const int gi = row0 + li, gj = col0 + lj;
         if (gi >= m || gj >= n) continue;
@@ -677,7 +680,7 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
         else        hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG, false, false>), dim3(grid), dim3(256), lds_bytes, st, a);
     }
     if (tail > 0) {
-        hipLaunchKernelGGL((tail_reduce_kernel<CPLX, C_::BM, C_::BN>), dim3((unsigned)tail), dim3(256), 0, st, ws,
+        hipLaunchKernelGGL((tail_reduce_kernel<CPLX, C_::BM, C_::BN>), dim3((unsigned)tail * TAIL_PARTS), dim3(256), 0, st, ws,
                            (int)full, sk, a.gn, m, n, C, ldc, a.alpha_re, a.alpha_im, a.beta_re, a.beta_im);
     }
     return (int)hipGetLastError();
