@@ -199,3 +199,17 @@ def test_oracle_reproduces_runs_of_the_actual_reference(N, cplx, nev, nex, iters
     assert (so["iterations"], so["filtered_vecs"]) == (iters, vecs)
     assert np.max(np.abs(k.ritzv[:nev] - (-N + 2.0 * np.arange(nev)))) < 1e-8
     assert np.max(k.resid[:nev]) <= 1e-10
+
+
+@pytest.mark.parametrize("tag,N", [("cdouble_tiny_random_BSE", 10), ("cdouble_random_BSE", 200)])
+def test_flip_lower_half_gives_the_fixture_SH_spectrum(tag, N):
+    """S H (lower half of the rows negated, flipLowerHalfMatrixSign) is Hermitian positive definite with the spectrum the
+    reference stores next to its BSE fixtures (SH_eigs_*.bin)."""
+    import os
+    from conftest import REF_FIX
+    H = read_ref_matrix(tag + ".bin", N, N, True)
+    want = np.sort(np.fromfile(os.path.join(REF_FIX, "SH_eigs_%s.bin" % tag), dtype=np.float64))      # N real values
+    SH = O.flip_lower_half(H.copy())
+    assert np.linalg.norm(SH - SH.conj().T) <= 1e-12 * np.linalg.norm(SH)
+    got = np.linalg.eigvalsh((SH + SH.conj().T) / 2)
+    assert got.min() > 0 and np.max(np.abs(got - want)) <= 1e-10 * np.abs(want).max()
