@@ -12,3 +12,6 @@ for f in cdouble_random_BSE cdouble_tiny_random_BSE; do
   cp "$REF/tests/linalg/internal/BSE_matrices/${f}.bin" "$REF/tests/linalg/internal/BSE_matrices/eigs_${f}.bin" \
      "$REF/tests/linalg/internal/BSE_matrices/SH_eigs_${f}.bin" "$OUT/"
 done
+for f in double_random_BSE double_tiny_random_BSE; do      # real pseudo-Hermitian fixtures [[A, B], [-B, -A]]
+  cp "$REF/tests/linalg/internal/BSE_matrices/${f}.bin" "$REF/tests/linalg/internal/BSE_matrices/eigs_${f}.bin" "$OUT/"
+done

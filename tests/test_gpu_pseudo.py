@@ -204,3 +204,32 @@ def test_lanczos_for_H2_reference_assertions_on_gpu(ctx):
     upperb, idx = s.lanczos_for_H2(numvec, m)
     _lanczos_for_H2_reference_assertions(eigs, nev + nex, m, upperb, idx, s.ritzv)
     s.close()
+
+
+def test_real_pseudo_hermitian_fixture_solve(ctx):
+    """The `double` instantiation of the pseudo-Hermitian path (ChASEGPU<double, PseudoHermitianMatrix>): the reference's
+    real BSE fixture [[A, B], [-B, -A]] (200 x 200) solved with ChaseHipPseudo<double>; smallest positive eigenvalues of
+    eigs_double_random_BSE.bin, residuals <= 1e-10, and the same iteration count as the oracle."""
+    import os
+    from conftest import REF_FIX
+    from chase_amd.capi import PseudoSolver
+    N, nev, nex = 200, 20, 20
+    H = read_ref_matrix("double_random_BSE.bin", N, N, False)
+    k = N // 2
+    assert np.array_equal(H[k:, :k], -H[:k, k:]) and np.array_equal(H[k:, k:], -H[:k, :k])
+    eigs = np.fromfile(os.path.join(REF_FIX, "eigs_double_random_BSE.bin"), dtype=np.float64)
+    pos = np.sort(eigs[eigs > 0])
+    s = PseudoSolver(ctx, H, nev, nex)
+    assert not s.cplx
+    s.set(tol=1e-10, numlanczos=10, lanczositer=50)
+    st = s.solve()
+    lam = s.ritzv[:nev].copy()
+    assert np.max(np.abs(np.sort(lam) - pos[:nev])) <= 1e-9
+    assert np.max(s.resid()[:nev]) <= 1e-10
+    V = s.V[:, :nev]
+    assert np.max(np.linalg.norm(H @ V - V * lam[None, :], axis=0)) <= 1e-9
+    ko = O.OraclePseudoCPU(H.astype(np.complex128), nev, nex); ko.config.num_lanczos = 10; ko.config.lanczos_iter = 50
+    so = O.solve_pseudo(ko)
+    assert np.max(np.abs(np.sort(ko.ritzv[:nev]) - pos[:nev])) <= 1e-9
+    assert abs(st["iterations"] - so["iterations"]) <= 2
+    s.close()
