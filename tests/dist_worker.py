@@ -339,6 +339,28 @@ def scenario_pseudo_ops(ctx, grid, rank, world, mb):
     s.close()
 
 
+def scenario_pseudo_solve_real(ctx, grid, rank, world, mb):
+    """the `double` instantiation of the grid pseudo-Hermitian Impl on the reference's real BSE fixture"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest
+    N, nev, nex = 200, 20, 20
+    H = conftest.read_ref_matrix("double_random_BSE.bin", N, N, False)
+    eigs = np.fromfile(os.path.join(conftest.REF_FIX, "eigs_double_random_BSE.bin"), dtype=np.float64)
+    pos = np.sort(eigs[eigs > 0])
+    rl, cl = cd.Layout(N, mb, grid.nprow), cd.Layout(N, mb, grid.npcol)
+    dH = ctx.array(cd.local_block_of(H, rl, cl, grid.myrow, grid.mycol))
+    s = cd.DistPseudoSolver(ctx, grid, dH, N, nev, nex, False, mb, mb)
+    s.set(tol=1e-10, deg=20, opt=1, maxiter=25, numlanczos=10, lanczositer=50)
+    st = s.solve()
+    lam = s.ritzv[:nev].copy()
+    assert np.max(s.resid()[:nev]) <= 1e-10
+    V = gathered_V(s, grid, rl, world, N, H.dtype)[:, :nev]
+    assert np.max(np.linalg.norm(H @ V - V * lam[None, :], axis=0)) <= 1e-9
+    assert np.max(np.abs(np.sort(lam) - pos[:nev])) <= 1e-9
+    assert st["locked"] >= nev
+    s.close()
+
+
 def scenario_pseudo_solve(ctx, grid, rank, world, mb):
     """chase::Solve_pseudo on the grid vs the reference's BSE integration test
     (tests/chase_distributed_solve_pseudo_bse_test.cpp; n = 200, nev = nex = 20, numLanczos 10, lanczosIter 50)."""
@@ -382,6 +404,8 @@ def main():
             scenario_symcheck(ctx, grid, rank, world, sys.argv[3] == "z", int(sys.argv[4]))
         elif scen == "pseudo_ops":
             scenario_pseudo_ops(ctx, grid, rank, world, int(sys.argv[3]))
+        elif scen == "pseudo_solve_real":
+            scenario_pseudo_solve_real(ctx, grid, rank, world, int(sys.argv[3]))
         elif scen == "pseudo_solve":
             scenario_pseudo_solve(ctx, grid, rank, world, int(sys.argv[3]))
         else:

@@ -97,3 +97,8 @@ def test_distributed_run_reproduces_the_reference_example_run():
     """examples/1_hello_world measured with the actual reference (pChASECPU, 2 x 2, block-cyclic nb = 64): 6 iterations,
     13 310 filtered vectors (BASELINE.md cross-check table)"""
     run_ranks(4, "host", "refcounts")
+
+
+@pytest.mark.parametrize("nranks,mb", [(4, 0), (2, 16)])
+def test_pseudo_solve_real_fixture(nranks, mb):
+    run_ranks(nranks, "host", "pseudo_solve_real", mb)
