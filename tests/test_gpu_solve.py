@@ -305,3 +305,22 @@ def test_c_interface_pseudo_hermitian(ctx):
     flag = C.c_int(0)
     lib.zchase_finalize_(C.byref(flag))
     assert flag.value == 1
+
+
+def test_plain_c_caller_of_the_c_interface(tmp_path):
+    """examples/c_serial_sequence.c: a C program (no Python, no C++) linked against libchase_hip.so through
+    include/chase_c_interface.h, with the life cycle of the reference's examples/4_interface/4_c_serial_chase.c —
+    init once, refill H in place, solve a sequence of three perturbed problems ('R' then 'A')."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_serial_sequence")
+    lib = os.path.join(root, "chase_amd", "lib")
+    subprocess.run(["gcc", "-O2", "-std=c11", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "c_serial_sequence.c"), "-L" + lib, "-lchase_hip",
+                    "-Wl,-rpath," + lib, "-lm", "-o", exe], check=True)
+    p = subprocess.run([exe, "600"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "C_SEQUENCE_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
