@@ -324,3 +324,22 @@ def test_plain_c_caller_of_the_c_interface(tmp_path):
                     "-Wl,-rpath," + lib, "-lm", "-o", exe], check=True)
     p = subprocess.run([exe, "600"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "C_SEQUENCE_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
+
+
+def test_cpp_caller_of_the_impl_classes(tmp_path):
+    """examples/hello_world.cpp: the header-only Impl (ChaseHip<T>) + driver compiled by a plain host compiler (g++, no
+    hipcc) against the C ABI, the way a ChASE application embeds an Impl (reference: examples/1_hello_world); it reproduces
+    the reference binary's 5 iterations / 12 664 filtered vectors on that example's matrix."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "hello_world")
+    lib = os.path.join(root, "chase_amd", "lib")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "chase_amd", "host"),
+                    os.path.join(root, "examples", "hello_world.cpp"), "-L" + lib, "-lchase_hip", "-Wl,-rpath," + lib,
+                    "-o", exe], check=True)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "HELLO_WORLD_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
