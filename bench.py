@@ -1,18 +1,30 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X-native ChASE hot path (contract: see the task prompt / DESIGN.md §6).
 
-A "step" is one complete ChASE solve (Lanczos bounds + filter / QR / Rayleigh-Ritz / residual iterations until nev
-pairs are locked) of the synthetic workload; the matrix is generated in HBM before the timed region.
-  metric  = Chebyshev-filter HEMM GFLOP/s  = 2*F*N^2*(filtered vectors) / time between FilterPhaseStart/End
-            (the reference's own model, algorithm/performance.hpp:248-260; F = 4 complex, 1 real)
-  extra   = eigenpairs_per_sec (nev / wall per solve), pct of the fp64 MFMA peak, per-phase seconds
-N = 1 workload: BASELINE.json configs[1]  (N = 16384 complex Hermitian fp64, nev = 512, nex = 128, one MI355X).
-N > 1: 2D block grid of the reference (grid/mpiGrid2D.hpp), one process per GPU, RCCL row/column all-reduces.
+Workload (every GPU count): BASELINE.json's metric configuration, configs[3] = "cfg4": N = 65536 complex Hermitian fp64,
+nev = 2048, nex = 512 (it fits one MI355X: H = 68.7 GB), so the 1 / 2 / 4 / 8 GPU values form a STRONG-scaling series.
+The matrix is generated in HBM before the timed region.
+
+A "step" is ONE OUTER ITERATION of the ChASE solve (Chebyshev filter + QR + Rayleigh-Ritz + residuals + locking,
+algorithm/algorithm.inc:1491-1720); whole solves run back to back and an iteration observer in the C++ driver
+(chase_hip_solver_set_iteration_hook) marks the iteration boundaries: W warm-up iterations are skipped, then EXACTLY K
+iterations are timed between two (device sync + barrier) brackets.  Everything a solve does before its first filter
+(start vectors, first QR, Lanczos bounds) belongs to that solve's first iteration.  A complete solve takes 9 iterations.
+  metric  = Chebyshev-filter HEMM GFLOP/s = flops of the reference's model (2*F*N^2 per filtered vector, F = 4 complex:
+            algorithm/performance.hpp:248-260) of the filter HEMMs of the timed iterations / HIP-event time between
+            FilterPhaseStart/End (max over ranks, all-reduces included), whole job
+  extra   = eigenpairs_per_sec (nev / wall of the complete solves), per-phase seconds, roofline (EXECUTED MFMA flops:
+            the complex filter kernel forms a complex product from 3 real MFMA products), the four-product kernel timed
+            on full-width HEMMs, the CPU oracle on the host cores.
+`python bench.py --gpus N` with N > 1 starts its N ranks itself (one process per GPU, RCCL row/column all-reduces over
+xGMI on the reference's 2D grid, grid/mpiGrid2D.hpp); under torch.distributed.run (RANK set) it is one of the ranks.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -29,13 +41,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X fp64 matrix == vector peak (vendor fi
 MATRIX_SCALE = 100.0
 MATRIX_PERTURB = 1e-6
 
-DEFAULT_WORKLOAD = "cfg2"
-# BASELINE.json assigns one configuration to each GPU count (configs[1] 1 GPU, configs[2] 4 GPUs, configs[3] 8 GPUs).
-# The default series keeps ONE arithmetic type (complex Hermitian, like the 1- and 8-GPU configurations) so that the
-# per-N values are comparable: 2 and 4 GPUs run the complex twin of configs[2] (same N, nev, nex; "cfg3c") on 2x1 / 2x2
-# grids; the real-symmetric configs[2] itself is --workload cfg3.  --workload overrides (e.g. cfg4 on every N for a
-# strong-scaling series).
-DEFAULT_BY_GPUS = {1: "cfg2", 2: "cfg3c", 4: "cfg3c", 8: "cfg4"}
+DEFAULT_WORKLOAD = "cfg4"                    # BASELINE.json "metric": N=64k nev=2048 — on every GPU count (strong scaling)
 DEFAULT_BLOCK_CYCLIC = {"cfg4": 64}          # BASELINE configs[3]: block-cyclic distribution (nb = 64, examples/1_hello_world)
 
 WORKLOADS = {
@@ -51,15 +57,7 @@ WORKLOADS = {
 }
 PSEUDO_WORKLOADS = {"cfg5"}
 BSE_MATRIX = {"dmin": 1.0, "dmax": 11.0, "offdiag": 1e-3}
-
-
-def mfma_executed_fraction(cplx, m_loc, k_loc):
-    """Share of the algorithmic (reference flop model, 4 real multiplications per complex one) flops the filter HEMM
-    actually executes on the matrix cores: 3/4 when the three-multiplication complex scheme applies."""
-    from chase_amd.capi import lib
-    if cplx and lib.chase_hip_gemm3m_enabled() and m_loc % 128 == 0 and k_loc % 8 == 0:
-        return 0.75
-    return 1.0
+PHASES = ("t_all", "t_init", "t_lanczos", "t_filter", "t_qr", "t_rr", "t_resid")
 
 
 def spectrum_check(lam, N, nev):
@@ -76,7 +74,7 @@ def spectrum_check(lam, N, nev):
 
 def cpu_baseline(N, cplx, ncols, budget_s=25.0):
     """Times the CPU oracle's filter HEMM (oracle/chase_oracle.py: OracleCPU.HEMM -> numpy/OpenBLAS gemm) on a bounded
-    sample of the same workload: full-height H, as many columns as fit the time budget."""
+    sample of the same workload: as many rows of H as the host comfortably holds, 128 columns."""
     from oracle import chase_oracle as O
     threads = os.cpu_count() or 1
     F = 4 if cplx else 1
@@ -100,7 +98,10 @@ def cpu_baseline(N, cplx, ncols, budget_s=25.0):
     dt = (time.perf_counter() - t0) / reps
     gflops = 2.0 * F * n_s * n_s * cols / dt / 1e9
     out = {"value": gflops, "unit": "GFLOP/s", "cores": threads, "kind": "port",
-           "sample": f"oracle HEMM (numpy/OpenBLAS zgemm)" if cplx else "oracle HEMM (numpy/OpenBLAS dgemm)",
+           "sample": ("oracle filter HEMM (numpy/OpenBLAS %s) on a %d x %d slice of the workload's operator times 128 of "
+                      "its %d columns, %d repetitions; a GEMM rate does not depend on the sample size, so this IS the "
+                      "rate the CPU path would sustain on the full N = %d workload (extrapolated from the sample, not "
+                      "measured at full size)") % ("zgemm" if cplx else "dgemm", n_s, n_s, ncols, reps, N),
            "sample_shape": {"N": n_s, "ncols": cols, "reps": reps, "seconds_per_call": dt}}
     # second bounded sample: one complete oracle solve of the reference's CPU-runnable configuration (BASELINE configs[0]:
     # N = 4096 real, nev = 100, nex = 40; the reference itself measured 5.44 s on 8 vCPU)
@@ -118,12 +119,145 @@ def cpu_baseline(N, cplx, ncols, budget_s=25.0):
     return out
 
 
+class StepTimer:
+    """Times exactly `steps` outer iterations after `warmup` untimed ones, across back-to-back solves.
+
+    sync(): device synchronisation of this rank; barrier(): all ranks; snapshot(): dict of cumulative counters.  The
+    boundaries are bracketed sync -> barrier -> clock on both sides, like the contract asks for whole steps."""
+
+    def __init__(self, steps, warmup, sync, barrier, snapshot):
+        self.steps, self.warmup = steps, warmup
+        self.sync, self.barrier, self.snapshot = sync, barrier, snapshot
+        self.boundary = 0                     # outer iterations completed so far (all solves)
+        self.t0 = self.t1 = None
+        self.c0 = self.c1 = None
+        self.filtered_timed = 0
+        self.per_iter = []                    # (solve index, iteration, filtered vectors, seconds since previous boundary)
+        self.solve_index = 0
+        self.complete_solves = 0
+        self._last = None
+
+    @property
+    def running(self):
+        return self.t0 is not None and self.t1 is None
+
+    @property
+    def done(self):
+        return self.t1 is not None
+
+    def _bracket(self):
+        self.sync()
+        self.barrier()
+        return time.perf_counter(), self.snapshot()
+
+    def start_if_due(self):
+        if self.t0 is None and self.boundary == self.warmup:
+            self.t0, self.c0 = self._bracket()
+            self._last = self.t0
+
+    def hook(self, it, filtered, locked, unconverged):
+        self.boundary += 1
+        if self.running:
+            self.filtered_timed += filtered
+            now = time.perf_counter()          # host clock only: informative per-iteration split, not the timed bracket
+            self.per_iter.append((self.solve_index, it, filtered, now - self._last))
+            self._last = now
+            if self.boundary == self.warmup + self.steps:
+                self.t1, self.c1 = self._bracket()
+        self.start_if_due()
+        # once the timed iterations are in and a complete solve exists for the parity guard, stop iterating
+        return self.done and self.complete_solves >= 1
+
+    def diff(self, key):
+        return self.c1[key] - self.c0[key]
+
+
+def run_timed_solves(s, timer, nev, capture):
+    """Back-to-back solves until the timer has its iterations.  capture() returns (eigenvalues, residuals) of the solver's
+    last solve; the last COMPLETE solve (all nev pairs locked) is what the parity guard checks."""
+    complete, last_complete = [], None
+    s.set_iteration_hook(timer.hook)
+    timer.start_if_due()
+    while True:
+        st = s.solve()
+        if st["locked"] >= nev:
+            timer.complete_solves += 1
+            complete.append(st)
+            last_complete = capture()
+        timer.solve_index += 1
+        if timer.done and timer.complete_solves >= 1:
+            break
+        if timer.solve_index > timer.warmup + timer.steps + 2:
+            raise RuntimeError("bench: solves do not converge (no complete solve within the iteration budget)")
+    s.set_iteration_hook(None)
+    return complete, last_complete
+
+
+def fullwidth_probe(s, ctx, N, cplx, nevex, three_m, reps=4):
+    """A few full-width filter HEMMs (phase-1 kernel symbol) timed with HIP events on the launch stream, with the
+    three-multiplication scheme on or off: the four-product run is the reference's zgemm arithmetic."""
+    from chase_amd.capi import lib, check, gemm_counters
+    lib.chase_hip_set_gemm3m(1 if three_m else 0)
+    try:
+        s.Start()
+        s.initVecs(True)
+        check(lib.chase_hip_ctx_set_phase(ctx.h, 1), "set_phase")
+        s.HEMM(nevex, 0.01, 0.0, 0)                      # untimed: first launch of this instantiation
+        s.HEMM(nevex, 0.01, -0.5, 0)
+        ctx.sync()
+        m0, e0, n0 = gemm_counters(ctx, 1)
+        ctx.timer_start()
+        for _ in range(reps):
+            s.HEMM(nevex, 0.01, -0.5, 0)
+        ms = ctx.timer_stop()
+        m1, e1, n1 = gemm_counters(ctx, 1)
+    finally:
+        check(lib.chase_hip_ctx_set_phase(ctx.h, 0), "set_phase")
+        lib.chase_hip_set_gemm3m(1)
+    model, execd = (m1 - m0) / (ms * 1e-3) / 1e12, (e1 - e0) / (ms * 1e-3) / 1e12
+    return {"bound": "mfma",
+            "kernel": "gemm_f64_kernel<cplx,op=N,TAG=1,%s> full-width filter HEMM (ncols = %d)" % ("3M" if three_m else "4M", nevex),
+            "achieved": execd, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": execd / FP64_MFMA_PEAK_TFLOPS,
+            "algorithmic": model, "launches": int(n1 - n0), "avg_launch_ms": ms / max(int(n1 - n0), 1), "traffic": None}
+
+
+def roofline_object(model_flops, exec_flops, filt_s, calls, world, note_extra=""):
+    """roofline of the dominant kernel: EXECUTED MFMA flops / HIP-event filter time / peak, per GPU (<= 1); the rate in the
+    reference's flop model (which `value` is quoted in) is `algorithmic`."""
+    execd = exec_flops / filt_s / 1e12 / world
+    model = model_flops / filt_s / 1e12 / world
+    return {"bound": "mfma", "kernel": "gemm_f64_kernel<cplx,op,TAG=1> (Chebyshev-filter HEMM), per GPU",
+            "achieved": execd, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": execd / FP64_MFMA_PEAK_TFLOPS,
+            "traffic": None, "algorithmic": model, "algorithmic_frac_of_peak": model / FP64_MFMA_PEAK_TFLOPS,
+            "executed_over_model": exec_flops / model_flops if model_flops else None,
+            "launches": calls, "avg_launch_ms": filt_s * 1e3 / max(calls, 1),
+            "flop_per_launch_avg": model_flops / max(calls, 1) / world,
+            "launch_unit": "one HEMM call per GPU = whole-tile kernel (+ ragged-column kernel when the width is not a "
+                           "multiple of the tile width) + tail reduce; rocprofv3: sum over the TAG=1 kernels",
+            "note": "achieved/frac = flops the matrix cores EXECUTE (the complex filter kernel forms each complex product "
+                    "from 3 real MFMA products, 3/4 of the reference model's 4) / HIP-event time between "
+                    "FilterPhaseStart/End on the launch stream; algorithmic = the reference's model "
+                    "2*F*N^2*ncols, F = 4 (the unit of `value`)" + note_extra}
+
+
+def attach_traffic(out, workload):
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            rec = json.load(open(pmc))
+            if rec.get("workload") == workload:
+                out["roofline"]["traffic"] = rec.get("hbm_bytes_per_launch")
+                out["roofline"]["traffic_note"] = rec.get("note")
+        except Exception:
+            pass
+
+
 def run_single(args):
-    from chase_amd.capi import Context, Solver, lib, check
+    from chase_amd.capi import Context, Solver, gemm_counters
     N, cplx, nev, nex = WORKLOADS[args.workload]
     if args.n:
         N = args.n
-    dt = np.complex128 if cplx else np.float64
+    nevex = nev + nex
     ctx = Context(0)
     info = ctx.info()
     dH = ctx.gen_clement(N, cplx, scale=MATRIX_SCALE / N, perturb=MATRIX_PERTURB, seed=42)
@@ -131,116 +265,153 @@ def run_single(args):
     s = Solver(ctx, None, nev, nex, h_on_device_ptr=dH.ptr, N=N, cplx=cplx)
     s.set(device_rng=1)
     F = 4 if cplx else 1
-    stats = []
-    for it in range(args.warmup):
-        s.set(reset_counters=1)
-        s.solve()
-    ctx.sync()
-    t0 = time.perf_counter()
-    for it in range(args.steps):
-        s.set(reset_counters=1)
-        st = s.solve()
-        st["hemm_calls"] = s.get("hemm_calls")
-        st["hemm_reused_vecs"] = s.get("hemm_reused_vecs")
-        stats.append(st)
-    ctx.sync()
-    wall = time.perf_counter() - t0
-    # vectors that went through a filter HEMM: the reference's count minus the first-step columns served from the
-    # Rayleigh-Ritz product - those cost O(N n), crediting them N^2 flops would inflate the rate
-    reused = sum(x["hemm_reused_vecs"] for x in stats)
-    vecs = sum(x["filtered_vecs"] for x in stats) - reused
-    filt_s = sum(x["filter_ms_device"] for x in stats) * 1e-3
-    calls = sum(x["hemm_calls"] for x in stats)
-    flops = 2.0 * F * N * N * vecs
-    gflops = flops / filt_s / 1e9
-    xf = mfma_executed_fraction(cplx, N, N)
-    # parity guard inside the bench: the timed solves must have converged to the solver tolerance
-    resid = s.resid()[:nev]
-    lam = s.ritzv[:nev].copy()
+
+    def snapshot():
+        model, execd, calls = gemm_counters(ctx, 1)
+        return {"filter_ms": s.get("filter_ms"), "hemm_calls": s.get("hemm_calls"),
+                "reused": s.get("hemm_reused_vecs"), "model": model, "exec": execd, "gemms": calls}
+
+    timer = StepTimer(args.steps, args.warmup, ctx.sync, lambda: None, snapshot)
+    complete, last = run_timed_solves(s, timer, nev, lambda: (s.ritzv[:nev].copy(), s.resid()[:nev].copy()))
+    wall = timer.t1 - timer.t0
+    filt_s = timer.diff("filter_ms") * 1e-3
+    calls = int(timer.diff("hemm_calls"))
+    reused = int(timer.diff("reused"))
+    model_flops, exec_flops = timer.diff("model"), timer.diff("exec")
+    hemm_vecs = timer.filtered_timed - reused
+    # the kernel-side books must agree with the reference's count: 2*F*N^2 per vector that went through a HEMM
+    formula = 2.0 * F * N * N * hemm_vecs
+    assert abs(model_flops - formula) <= 1e-9 * formula, (model_flops, formula)
+    gflops = model_flops / filt_s / 1e9
+    lam, resid = last
     spec = spectrum_check(lam, N, nev)
-    ok = bool(np.all(np.isfinite(lam)) and np.max(resid) < 1e-8 and stats[-1]["locked"] >= nev and spec["ok"])
-    last = stats[-1]
+    ok = bool(np.all(np.isfinite(lam)) and np.max(resid) < 1e-8 and spec["ok"])
+    st = complete[-1]
+    solve_s = float(np.mean([c["t_all"] for c in complete]))
     out = {
         "metric": "chebyshev_filter_hemm_gflops", "value": gflops, "unit": "GFLOP/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong" if args.user_workload else "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "complex f64" if cplx else "f64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: ChASE solve, perturbed Clement-type Hermitian (x100/N) N={N} "
-                               f"{'complex' if cplx else 'real'} fp64, nev={nev} nex={nex}, tol 1e-10, deg 20 opt, 1x1 grid",
-                   "N": N, "nev": nev, "nex": nex, "grid": "1x1"},
-        "eigenpairs_per_sec": nev / (wall / args.steps),
-        "pct_fp64_mfma_peak": 100.0 * xf * gflops / 1e3 / FP64_MFMA_PEAK_TFLOPS,
-        "mfma_executed_fraction": xf,
+                               f"{'complex' if cplx else 'real'} fp64, nev={nev} nex={nex}, tol 1e-10, deg 20 opt, 1x1 grid; "
+                               "step = one outer iteration (filter+QR+RR+residuals+locking), solves back to back",
+                   "N": N, "nev": nev, "nex": nex, "grid": "1x1", "step": "outer iteration"},
+        "eigenpairs_per_sec": nev / solve_s, "solve_seconds": solve_s, "complete_solves": len(complete),
+        "pct_fp64_mfma_peak": 100.0 * exec_flops / filt_s / 1e12 / FP64_MFMA_PEAK_TFLOPS,
         "converged": ok, "max_resid": float(np.max(resid)), "spectrum_check": spec,
-        "iterations": last["iterations"], "filtered_vecs_per_solve": (vecs + reused) / args.steps,
-        "hemm_vecs_per_solve": vecs / args.steps, "first_step_vecs_from_rr_per_solve": reused / args.steps,
-        "phase_seconds_last_solve": {k: last[k] for k in ("t_all", "t_init", "t_lanczos", "t_filter", "t_qr", "t_rr", "t_resid")},
+        "iterations_per_solve": st["iterations"], "filtered_vecs_per_solve": st["filtered_vecs"],
+        "timed": {"filtered_vecs": timer.filtered_timed, "hemm_vecs": hemm_vecs, "first_step_vecs_from_rr": reused,
+                  "filter_seconds_device": filt_s, "wall_seconds": wall,
+                  "iterations": [{"solve": a, "iteration": b, "filtered_vecs": c, "seconds": d} for a, b, c, d in timer.per_iter]},
+        "phase_seconds_last_complete_solve": {k: st[k] for k in PHASES},
         "device": info["name"],
-        "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<cplx,op=N,TAG=1> (filter HEMM)",
-                     "achieved": gflops / 1e3, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": gflops / 1e3 / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                     "executed": xf * gflops / 1e3, "executed_frac": xf * gflops / 1e3 / FP64_MFMA_PEAK_TFLOPS,
-                     "note": "achieved = ALGORITHMIC flops (reference model 2*F*N^2*ncols, F = 4 complex) / time; the "
-                             "complex filter kernel forms each complex product from 3 real MFMA products (3M), so the "
-                             "matrix cores execute `executed` = 3/4 of that; executed_frac is the MFMA utilisation",
-                     "launches": calls, "avg_launch_ms": filt_s * 1e3 / max(calls, 1),
-                     "launch_unit": "one HEMM call = whole-tile kernel (+ ragged-column kernel when the width is not a "
-                                    "multiple of the tile width) + tail reduce; rocprofv3: sum over the TAG=1 kernels",
-                     "flop_per_launch_avg": flops / max(calls, 1)},
+        "roofline": roofline_object(model_flops, exec_flops, filt_s, calls, 1),
     }
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            rec = json.load(open(pmc))
-            if rec.get("workload") == args.workload:
-                out["roofline"]["traffic"] = rec.get("hbm_bytes_per_launch")
-        except Exception:
-            pass
+    attach_traffic(out, args.workload)
+    if not args.no_probe and cplx:
+        # reference arithmetic (four real products per complex product, the reference's zgemm) on the same launch shape
+        out["roofline_4m"] = fullwidth_probe(s, ctx, N, cplx, nevex, three_m=False)
+        out["roofline_3m_fullwidth"] = fullwidth_probe(s, ctx, N, cplx, nevex, three_m=True)
     s.close()
+    del dH
     ctx.close()
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(N, cplx, nev + nex, args.cpu_budget)
+        out["cpu_baseline"] = cpu_baseline(N, cplx, nevex, args.cpu_budget)
     return out
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start N ranks of this script as child processes — one per
+    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set like torch.distributed.run does (the reference bootstraps its own
+    communicators too, grid/mpiGrid2D.hpp:448-484).  Nothing in this parent has touched HIP or torch.  Rank 0's JSON line
+    is relayed as the last line of stdout; the exit status is non-zero if any rank failed."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    n = args.gpus
+    procs, outs = [], []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        f = tempfile.TemporaryFile(mode="w+") if r == 0 else None
+        outs.append(f)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=f if f is not None else sys.stderr, stderr=sys.stderr))
+    rc = 0
+    try:
+        alive = set(range(n))
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench: rank {r} exited with status {code}; stopping the other ranks", file=sys.stderr)
+                    for q in alive:
+                        procs[q].terminate()           # exactly the processes started above
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    outs[0].seek(0)
+    lines = [l.rstrip("\n") for l in outs[0].read().splitlines() if l.strip()]
+    js = [l for l in lines if l.startswith("{") and l.endswith("}")]
+    for l in lines:
+        if not js or l is not js[-1]:
+            print(l, file=sys.stderr)
+    if rc == 0 and not js:
+        print("bench: rank 0 produced no result line", file=sys.stderr)
+        rc = 1
+    if js and rc == 0:
+        print(js[-1], flush=True)
+    return rc
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default=None)
+    # defaults: 3 warm-up + 6 timed iterations = the 9 iterations of one complete cfg4 solve (minutes on one GPU)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--n", "--size", dest="n", type=int, default=0, help="override N (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="skip the full-width 4M / 3M kernel probes")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
     ap.add_argument("--dist", action="store_true",
                     help="run the grid Impl (pChaseHip) even on one GPU (1x1 grid; development: panel-pipeline overheads)")
     ap.add_argument("--block-cyclic", type=int, default=-1,
                     help="block size of a block-cyclic H distribution (0 = block layout, -1 = the workload's default)")
     args = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if (args.workload in PSEUDO_WORKLOADS or args.dist) and world == 1 and args.gpus <= 1:
-        # the pseudo-Hermitian workload runs the grid Impl on a 1x1 grid (communicator-free) when launched directly
-        import socket
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
-        os.environ.setdefault("RANK", "0"); os.environ.setdefault("LOCAL_RANK", "0")
-        os.environ["WORLD_SIZE"] = "1"
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(port))
-        args.gpus = 1
-        world = 1
-        from chase_amd.dist_bench import run_distributed
-        print(json.dumps(run_distributed(args)), flush=True)
-        return
-    if args.gpus > 1 or world > 1:
+    if args.steps < 1 or args.warmup < 0:
+        ap.error("need --steps >= 1 and --warmup >= 0")
+    if args.workload is None:
+        args.workload = DEFAULT_WORKLOAD
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        # BEFORE anything initialises HIP / torch in this process
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    if world > 1 or args.dist or args.workload in PSEUDO_WORKLOADS:
+        if not launched:
+            # grid Impl on a 1x1 grid (communicator-free) when started directly on one GPU
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         from chase_amd.dist_bench import run_distributed
         out = run_distributed(args)
         if out is not None:
             print(json.dumps(out), flush=True)
         return
-    args.user_workload = args.workload is not None
-    if args.workload is None:
-        args.workload = DEFAULT_WORKLOAD
     out = run_single(args)
     print(json.dumps(out), flush=True)
 

@@ -274,6 +274,10 @@ _sig("chase_hip_solver_destroy", c_int, c_void_p)
 _sig("chase_hip_solver_set", c_int, c_void_p, C.c_char_p, c_double)
 _sig("chase_hip_solver_get", c_int, c_void_p, C.c_char_p, P(c_double))
 _sig("chase_hip_solver_solve", c_int, c_void_p, c_int)
+ITER_FN = C.CFUNCTYPE(c_int, c_void_p, c_size_t, c_size_t, c_size_t, c_size_t)
+_sig("chase_hip_solver_set_iteration_hook", c_int, c_void_p, ITER_FN, c_void_p)
+_sig("chase_hip_set_gemm3m", c_int, c_int)
+_sig("chase_hip_ctx_gemm_counters", c_int, c_void_p, c_int, P(c_double), P(c_double), P(C.c_ulonglong), c_int)
 _sig("chase_hip_solver_stats", c_int, c_void_p, P(Stats))
 _sig("chase_hip_solver_resid", P(c_double), c_void_p)
 _sig("chase_hip_solver_trace", C.c_char_p, c_void_p)
@@ -292,6 +296,28 @@ _sig("chase_hip_op_lock", c_int, c_void_p, c_size_t)
 _sig("chase_hip_op_lanczos", c_int, c_void_p, c_size_t, c_size_t, P(c_double), c_void_p, c_void_p, c_void_p)
 _sig("chase_hip_op_lanczos_dos", c_int, c_void_p, c_size_t, c_size_t, c_void_p)
 _sig("chase_hip_op_check_symmetry", c_int, c_void_p, P(c_int))
+
+
+def set_iteration_hook(solver, fn):
+    """Installs fn(iteration, filtered_vecs, locked, unconverged) as the outer-iteration observer of a solver object."""
+    if fn is None:
+        solver._iter_cb = ITER_FN()
+    else:
+        def _cb(user, it, filtered, locked, unconverged):
+            try:
+                return 1 if fn(int(it), int(filtered), int(locked), int(unconverged)) else 0
+            except Exception as e:  # pragma: no cover - never unwind through the C++ driver
+                print("iteration hook failed:", repr(e), flush=True)
+                return 1
+        solver._iter_cb = ITER_FN(_cb)                 # keep the thunk alive
+    check(lib.chase_hip_solver_set_iteration_hook(solver.h, solver._iter_cb, None), "set_iteration_hook")
+
+
+def gemm_counters(ctx, phase, reset=False):
+    """(model flops, executed flops, products) of the GEMMs a context issued in `phase` (1 = Chebyshev filter)."""
+    a, b, n = c_double(), c_double(), C.c_ulonglong()
+    check(lib.chase_hip_ctx_gemm_counters(ctx.h, phase, C.byref(a), C.byref(b), C.byref(n), int(reset)), "gemm_counters")
+    return a.value, b.value, n.value
 
 
 class Solver:
@@ -337,6 +363,10 @@ class Solver:
     def solve(self, trace=False):
         check(lib.chase_hip_solver_solve(self.h, int(trace)), "solver_solve")
         return self.stats()
+
+    def set_iteration_hook(self, fn):
+        """fn(iteration, filtered_vecs, locked, unconverged) -> truthy to leave the iteration loop; None removes it."""
+        set_iteration_hook(self, fn)
 
     def stats(self):
         s = Stats()

@@ -41,12 +41,8 @@ int gemm(chase_hip_ctx* c, int cplx, char op, int m, int n, int k, double ar, do
          const double* B, long ldb, double br, double bi, double* C, long ldc)
 {
     if (m <= 0 || n <= 0) return 0;
-    RCCHK(c->ensure_ws(WS_DEFAULT));
     const double alpha[2] = {ar, ai}, beta[2] = {br, bi};
-    int e = gemm_f64(c->stream, cplx != 0, op, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, (double*)c->ws,
-                     c->ws_bytes, c->num_cu, c->phase);
-    if (e) return hip_fail((hipError_t)e, "gemm launch");
-    return 0;
+    return c->gemm(cplx != 0, op, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
 }
 } // namespace
 
@@ -93,6 +89,7 @@ int chase_hip_set_host_threads(int n)
 int chase_hip_ctx_set_phase(chase_hip_ctx* c, int phase)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "set_phase: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     c->phase = phase;
     return 0;
 }
@@ -102,6 +99,7 @@ int chase_hip_fill_normal(chase_hip_ctx* c, int cplx, int m, int n, void* X, lon
                           unsigned long long seed)
 {
     if (!c || !X) return set_error(CHASE_HIP_EINVAL, "fill_normal: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (m < 0 || n < 0 || ldx < m) return set_error(CHASE_HIP_EINVAL, "fill_normal: bad shape");
     KCHK(fill_normal(c->stream, cplx != 0, (double*)X, ldx, m, n, grow0, gcol0, gld, seed), "fill_normal");
     return 0;
@@ -112,6 +110,7 @@ int chase_hip_fill_normal_bc(chase_hip_ctx* c, int cplx, int m, int n, void* X, 
                              int pi, unsigned long long seed)
 {
     if (!c || !X) return set_error(CHASE_HIP_EINVAL, "fill_normal_bc: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (m < 0 || n < 0 || ldx < m || mb <= 0 || pr <= 0) return set_error(CHASE_HIP_EINVAL, "fill_normal_bc: bad shape");
     KCHK(fill_normal(c->stream, cplx != 0, (double*)X, ldx, m, n, 0, 0, gld, seed, mb, pr, pi), "fill_normal_bc");
     return 0;
@@ -122,6 +121,7 @@ int chase_hip_rows_indexed(chase_hip_ctx* c, int cplx, const void* in, long ld_i
                            const int* idx_dev, int np, int ncols, int scatter)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "rows_indexed: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     KCHK(rows_indexed(c->stream, cplx != 0, (const double*)in, ld_in, (double*)out, ld_out, idx_dev, np, ncols, scatter),
          "rows_indexed");
     return 0;
@@ -135,6 +135,7 @@ int chase_hip_gen_clement(chase_hip_ctx* c, int cplx, void* H, long ldh, int mlo
                           unsigned long long seed)
 {
     if (!c || !H) return set_error(CHASE_HIP_EINVAL, "gen_clement: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (mloc < 0 || nloc < 0 || ldh < mloc || mb <= 0 || nb <= 0 || pr <= 0 || pc <= 0)
         return set_error(CHASE_HIP_EINVAL, "gen_clement: bad shape");
     KCHK(gen_clement(c->stream, cplx != 0, (double*)H, ldh, mloc, nloc, N, mb, pr, pi, roff, nb, pc, pj, coff, scale,
@@ -147,6 +148,7 @@ int chase_hip_gen_bse(chase_hip_ctx* c, int cplx, void* H, long ldh, int mloc, i
                       int nb, int pc, int pj, double dmin, double dmax, double offdiag, unsigned long long seed)
 {
     if (!c || !H) return set_error(CHASE_HIP_EINVAL, "gen_bse: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (mloc < 0 || nloc < 0 || ldh < mloc || mb <= 0 || nb <= 0 || pr <= 0 || pc <= 0 || N <= 0 || N % 2)
         return set_error(CHASE_HIP_EINVAL, "gen_bse: bad shape (N must be even)");
     KCHK(gen_bse(c->stream, cplx != 0, (double*)H, ldh, mloc, nloc, N, mb, pr, pi, nb, pc, pj, dmin, dmax, offdiag, seed),
@@ -157,6 +159,7 @@ int chase_hip_gen_bse(chase_hip_ctx* c, int cplx, void* H, long ldh, int mloc, i
 int chase_hip_shift_diag(chase_hip_ctx* c, int cplx, int n, void* H, long ldh, double shift)
 {
     if (!c || (!H && n > 0)) return set_error(CHASE_HIP_EINVAL, "shift_diag: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (n < 0 || ldh < n) return set_error(CHASE_HIP_EINVAL, "shift_diag: bad shape");
     KCHK(shift_diag(c->stream, (double*)H, ldh, n, ept_of(cplx), shift), "shift_diag");
     return 0;
@@ -166,6 +169,7 @@ int chase_hip_shift_list(chase_hip_ctx* c, int cplx, void* H, long ldh, const in
                          double shift)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "shift_list: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (cnt < 0) return set_error(CHASE_HIP_EINVAL, "shift_list: negative count");
     KCHK(shift_list(c->stream, (double*)H, ldh, rows_dev, cols_dev, cnt, ept_of(cplx), shift), "shift_list");
     return 0;
@@ -174,6 +178,7 @@ int chase_hip_shift_list(chase_hip_ctx* c, int cplx, void* H, long ldh, const in
 int chase_hip_lacpy(chase_hip_ctx* c, int cplx, int m, int n, const void* A, long lda, void* B, long ldb)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "lacpy: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (m < 0 || n < 0 || lda < m || ldb < m) return set_error(CHASE_HIP_EINVAL, "lacpy: bad shape");
     if (m == 0 || n == 0) return 0;
     const int e = ept_of(cplx);
@@ -184,6 +189,7 @@ int chase_hip_lacpy(chase_hip_ctx* c, int cplx, int m, int n, const void* A, lon
 int chase_hip_swap_cols(chase_hip_ctx* c, int cplx, int m, void* V, long ldv, long i, long j)
 {
     if (!c || !V) return set_error(CHASE_HIP_EINVAL, "swap_cols: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (i == j) return 0;
     const int e = ept_of(cplx);
     double* v = (double*)V;
@@ -197,6 +203,7 @@ int chase_hip_permute_cols(chase_hip_ctx* c, int cplx, int m, void* V, long ldv,
                            const int* src_host, const int* dst_host, int cnt)
 {
     if (!c || !V || !scratch) return set_error(CHASE_HIP_EINVAL, "permute_cols: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (cnt <= 0) return 0;
     const int e = ept_of(cplx);
     RCCHK(c->ensure_buf(chase_hip_ctx::BUF_LAMBDA, (size_t)2 * cnt * sizeof(int) + 64));
@@ -217,6 +224,7 @@ int chase_hip_permute_cols(chase_hip_ctx* c, int cplx, int m, void* V, long ldv,
 int chase_hip_upload_matrix(chase_hip_ctx* c, int cplx, int m, int n, const void* host, long ldh, void* dev, long ldd)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "upload_matrix: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (m <= 0 || n <= 0) return 0;
     const size_t es = sizeof(double) * ept_of(cplx);
     HIPCHK(hipMemcpy2DAsync(dev, (size_t)ldd * es, host, (size_t)ldh * es, (size_t)m * es, n, hipMemcpyHostToDevice,
@@ -227,6 +235,7 @@ int chase_hip_upload_matrix(chase_hip_ctx* c, int cplx, int m, int n, const void
 int chase_hip_download_matrix(chase_hip_ctx* c, int cplx, int m, int n, const void* dev, long ldd, void* host, long ldh)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "download_matrix: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (m <= 0 || n <= 0) return 0;
     const size_t es = sizeof(double) * ept_of(cplx);
     HIPCHK(hipMemcpy2DAsync(host, (size_t)ldh * es, dev, (size_t)ldd * es, (size_t)m * es, n, hipMemcpyDeviceToHost,
@@ -238,6 +247,7 @@ int chase_hip_download_matrix(chase_hip_ctx* c, int cplx, int m, int n, const vo
 int chase_hip_scale_rows(chase_hip_ctx* c, int cplx, int m, int n, void* X, long ldx, int row0, double s)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "scale_rows: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     const int e = ept_of(cplx);
     KCHK(scale_rows(c->stream, (double*)X, ldx * e, (long)row0 * e, (long)m * e, n, s), "scale_rows");
     return 0;
@@ -247,6 +257,7 @@ int chase_hip_scale_rows_bc(chase_hip_ctx* c, int cplx, int m, int n, void* X, l
                             double s)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "scale_rows_bc: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (nb <= 0 || p <= 0 || q < 0 || q >= p || (n > 0 && ldx < m)) return set_error(CHASE_HIP_EINVAL, "scale_rows_bc: bad layout");
     const int e = ept_of(cplx);
     KCHK(scale_rows_bc(c->stream, (double*)X, ldx * e, (long)m, n, e, g0, nb, p, q, s), "scale_rows_bc");
@@ -256,6 +267,7 @@ int chase_hip_scale_rows_bc(chase_hip_ctx* c, int cplx, int m, int n, void* X, l
 int chase_hip_conj(chase_hip_ctx* c, int m, int n, void* X, long ldx)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "conj: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     KCHK(conj_inplace(c->stream, (double*)X, ldx * 2, m, n), "conj");
     return 0;
 }
@@ -264,6 +276,7 @@ int chase_hip_conj(chase_hip_ctx* c, int m, int n, void* X, long ldx)
 int chase_hip_herk(chase_hip_ctx* c, int cplx, int n, int k, const void* V, long ldv, void* A, long lda)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "herk: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (n < 0 || k < 0 || ldv < (k > 1 ? k : 1) || lda < n) return set_error(CHASE_HIP_EINVAL, "herk: bad shape");
     return gemm(c, cplx, 'C', n, n, k, 1.0, 0.0, (const double*)V, ldv, (const double*)V, ldv, 0.0, 0.0, (double*)A,
                 lda);
@@ -272,6 +285,7 @@ int chase_hip_herk(chase_hip_ctx* c, int cplx, int n, int k, const void* V, long
 int chase_hip_abs_trace(chase_hip_ctx* c, int cplx, int n, const void* A, long lda, double* out_host)
 {
     if (!c || !out_host) return set_error(CHASE_HIP_EINVAL, "abs_trace: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     RCCHK(c->ensure_buf(chase_hip_ctx::BUF_SCAL, 4096));
     double* d = (double*)c->bufs[chase_hip_ctx::BUF_SCAL];
     KCHK(abs_trace(c->stream, (const double*)A, lda, n, ept_of(cplx), d), "abs_trace");
@@ -285,6 +299,7 @@ int chase_hip_abs_trace(chase_hip_ctx* c, int cplx, int n, const void* A, long l
 int chase_hip_potrf_upper(chase_hip_ctx* c, int cplx, int n, void* A_, long lda)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "potrf: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (n < 0 || lda < n) return set_error(CHASE_HIP_EINVAL, "potrf: bad shape");
     if (n == 0) return 0;
     const int e = ept_of(cplx);
@@ -321,6 +336,7 @@ int chase_hip_potrf_upper(chase_hip_ctx* c, int cplx, int n, void* A_, long lda)
 int chase_hip_trsm_right_upper(chase_hip_ctx* c, int cplx, int m, int n, const void* R_, long ldr, void* V_, long ldv)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "trsm: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (m < 0 || n < 0 || ldr < n || ldv < m) return set_error(CHASE_HIP_EINVAL, "trsm: bad shape");
     if (m == 0 || n == 0) return 0;
     const int e = ept_of(cplx);
@@ -357,6 +373,7 @@ int chase_hip_cholqr(chase_hip_ctx* c, int cplx, int m, int n, void* V, long ldv
                      long m_global)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "cholqr: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (variant < 1 || variant > 3) return set_error(CHASE_HIP_EINVAL, "cholqr: variant must be 1, 2 or 3");
     if (n == 0 || m == 0) return 0;
     int info;
@@ -386,6 +403,7 @@ int chase_hip_resid_norms(chase_hip_ctx* c, int cplx, int m, int n, const void* 
                           const double* lambda_host, double* resid_host, int squared)
 {
     if (!c || !resid_host || (V && !lambda_host)) return set_error(CHASE_HIP_EINVAL, "resid_norms: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (n <= 0) return 0;
     const int e = ept_of(cplx);
     RCCHK(c->ensure_buf(chase_hip_ctx::BUF_LAMBDA, (size_t)2 * n * sizeof(double)));
@@ -407,6 +425,7 @@ extern "C" int chase_hip_heevd_gpu(chase_hip_ctx* c, int cplx, int n, void* A, l
 int chase_hip_heevd(chase_hip_ctx* c, int cplx, int n, void* A, long lda, double* w_host)
 {
     if (!c || !w_host) return set_error(CHASE_HIP_EINVAL, "heevd: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (n < 0 || lda < n) return set_error(CHASE_HIP_EINVAL, "heevd: bad shape");
     if (n == 0) return 0;
     {   // large projected problems: tridiagonalise and back-transform on the GPU, only the O(n^2) tridiagonal solve on
@@ -433,6 +452,7 @@ int chase_hip_heevd(chase_hip_ctx* c, int cplx, int n, void* A, long lda, double
 int chase_hip_pseudo_rr_small(chase_hip_ctx* c, int cplx, int n, void* A_dev, void* M_dev, double* ritzv_host)
 {
     if (!c || !A_dev || !M_dev || !ritzv_host) return set_error(CHASE_HIP_EINVAL, "pseudo_rr_small: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (n <= 0) return 0;
     const size_t bytes = (size_t)n * n * sizeof(double) * ept_of(cplx);
     RCCHK(c->ensure_hstage(2 * bytes));
@@ -452,6 +472,7 @@ int chase_hip_pseudo_rr_small(chase_hip_ctx* c, int cplx, int n, void* A_dev, vo
 int chase_hip_set_identity(chase_hip_ctx* c, int cplx, int n, void* A, long lda)
 {
     if (!c || !A) return set_error(CHASE_HIP_EINVAL, "set_identity: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     HIPCHK(hipMemset2DAsync(A, (size_t)lda * sizeof(double) * ept_of(cplx), 0, (size_t)n * sizeof(double) * ept_of(cplx), n, c->stream));
     KCHK(shift_diag(c->stream, (double*)A, lda, n, ept_of(cplx), 1.0), "set_identity");
     return 0;
@@ -475,6 +496,7 @@ int chase_hip_col_dot(chase_hip_ctx* c, int cplx, int m, int n, const void* X, l
                       double* out_dev)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "col_dot: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     const int e = ept_of(cplx);
     KCHK(col_dot(c->stream, cplx != 0, (const double*)X, ldx * e, (const double*)Y, ldy * e, m, n, out_dev), "col_dot");
     return 0;
@@ -482,6 +504,7 @@ int chase_hip_col_dot(chase_hip_ctx* c, int cplx, int m, int n, const void* X, l
 int chase_hip_col_nrm2(chase_hip_ctx* c, int cplx, int m, int n, const void* X, long ldx, double* out_dev)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "col_nrm2: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     const int e = ept_of(cplx);
     KCHK(resid_norms(c->stream, (const double*)X, ldx * e, nullptr, 0, nullptr, (long)m * e, n, out_dev, 1), "col_nrm2");
     return 0;
@@ -490,6 +513,7 @@ int chase_hip_col_nrm2(chase_hip_ctx* c, int cplx, int m, int n, const void* X, 
 int chase_hip_col_sumsq(chase_hip_ctx* c, int cplx, int m, int n, const void* X, long ldx, double* out_dev)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "col_sumsq: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     const int e = ept_of(cplx);
     KCHK(resid_norms(c->stream, (const double*)X, ldx * e, nullptr, 0, nullptr, (long)m * e, n, out_dev, 0), "col_sumsq");
     return 0;
@@ -497,6 +521,7 @@ int chase_hip_col_sumsq(chase_hip_ctx* c, int cplx, int m, int n, const void* X,
 int chase_hip_sqrt_inplace(chase_hip_ctx* c, double* x_dev, int n)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "sqrt_inplace: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     KCHK(sqrt_inplace(c->stream, x_dev, n), "sqrt_inplace");
     return 0;
 }
@@ -504,6 +529,7 @@ int chase_hip_col_axpy(chase_hip_ctx* c, int cplx, int m, int n, const double* a
                        double sgn, const void* X, long ldx, void* Y, long ldy)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "col_axpy: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     const int e = ept_of(cplx);
     KCHK(col_axpy(c->stream, cplx != 0, a_dev, a_is_real, a_stride, sgn, (const double*)X, ldx * e, (double*)Y, ldy * e,
                   m, n), "col_axpy");
@@ -512,6 +538,7 @@ int chase_hip_col_axpy(chase_hip_ctx* c, int cplx, int m, int n, const double* a
 int chase_hip_col_scal(chase_hip_ctx* c, int cplx, int m, int n, const double* a_dev, int inverse, void* X, long ldx)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "col_scal: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     const int e = ept_of(cplx);
     KCHK(col_scal(c->stream, a_dev, inverse, (double*)X, ldx * e, (long)m * e, n), "col_scal");
     return 0;
@@ -521,12 +548,14 @@ int chase_hip_col_scal(chase_hip_ctx* c, int cplx, int m, int n, const double* a
 int chase_hip_pack_upper(chase_hip_ctx* c, int cplx, int n, const void* A, long lda, void* P)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "pack_upper: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     KCHK(pack_upper(c->stream, (const double*)A, lda, n, ept_of(cplx), (double*)P), "pack_upper");
     return 0;
 }
 int chase_hip_unpack_upper(chase_hip_ctx* c, int cplx, int n, const void* P, void* A, long lda, int mirror)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "unpack_upper: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     KCHK(unpack_upper(c->stream, (double*)P, n, ept_of(cplx), (double*)A, lda), "unpack_upper");
     if (mirror) KCHK(mirror_upper(c->stream, (double*)A, lda, n, ept_of(cplx)), "mirror_upper");
     return 0;

@@ -91,6 +91,7 @@ int chase_hip_ctx_destroy(chase_hip_ctx* c)
 int chase_hip_ctx_sync(chase_hip_ctx* c)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "ctx == NULL");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -100,6 +101,7 @@ void* chase_hip_ctx_stream(chase_hip_ctx* c) { return c ? (void*)c->stream : nul
 int chase_hip_device_info(chase_hip_ctx* c, int* num_cu, int* clock_khz, size_t* hbm_bytes, char* name, int name_len)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "ctx == NULL");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (num_cu) *num_cu = c->num_cu;
     if (clock_khz) *clock_khz = c->clock_khz;
     if (hbm_bytes) *hbm_bytes = c->hbm_bytes;
@@ -113,6 +115,7 @@ int chase_hip_device_info(chase_hip_ctx* c, int* num_cu, int* clock_khz, size_t*
 int chase_hip_malloc(chase_hip_ctx* c, void** dev, size_t bytes)
 {
     if (!c || !dev) return set_error(CHASE_HIP_EINVAL, "malloc: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     HIPCHK(hipSetDevice(c->device));
     hipError_t e = hipMalloc(dev, bytes ? bytes : 16);
     if (e == hipErrorOutOfMemory) return set_error(CHASE_HIP_ENOMEM, "hipMalloc: out of memory");
@@ -122,6 +125,7 @@ int chase_hip_malloc(chase_hip_ctx* c, void** dev, size_t bytes)
 int chase_hip_free(chase_hip_ctx* c, void* dev)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "ctx == NULL");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (dev) {
         HIPCHK(hipStreamSynchronize(c->stream));
         HIPCHK(hipFree(dev));
@@ -131,6 +135,7 @@ int chase_hip_free(chase_hip_ctx* c, void* dev)
 int chase_hip_memcpy_h2d(chase_hip_ctx* c, void* dev, const void* host, size_t bytes)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "ctx == NULL");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     HIPCHK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
@@ -138,6 +143,7 @@ int chase_hip_memcpy_h2d(chase_hip_ctx* c, void* dev, const void* host, size_t b
 int chase_hip_memcpy_d2h(chase_hip_ctx* c, void* host, const void* dev, size_t bytes)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "ctx == NULL");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
@@ -145,24 +151,28 @@ int chase_hip_memcpy_d2h(chase_hip_ctx* c, void* host, const void* dev, size_t b
 int chase_hip_memcpy_d2d(chase_hip_ctx* c, void* dst, const void* src, size_t bytes)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "ctx == NULL");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 int chase_hip_memset(chase_hip_ctx* c, void* dev, int value, size_t bytes)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "ctx == NULL");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     HIPCHK(hipMemsetAsync(dev, value, bytes, c->stream));
     return 0;
 }
 int chase_hip_timer_start(chase_hip_ctx* c)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "ctx == NULL");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     return 0;
 }
 int chase_hip_timer_stop(chase_hip_ctx* c, float* ms)
 {
     if (!c || !ms) return set_error(CHASE_HIP_EINVAL, "timer_stop: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev1));
     HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
@@ -188,40 +198,45 @@ int chase_hip_gemm_d(chase_hip_ctx* c, char opA, int m, int n, int k, double alp
                      const double* B, long ldb, double beta, double* C, long ldc)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "ctx == NULL");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     int rc = check_gemm(opA, m, n, k, A, lda, B, ldb, C, ldc);
     if (rc) return rc;
-    rc = c->ensure_ws((size_t)640 << 20);
-    if (rc) return rc;
-    int e = gemm_f64(c->stream, false, opA, m, n, k, &alpha, A, lda, B, ldb, &beta, C, ldc, (double*)c->ws,
-                     c->ws_bytes, c->num_cu, c->phase);
-    if (e) return hip_fail((hipError_t)e, "gemm_d launch");
-    return 0;
+    return c->gemm(false, opA, m, n, k, &alpha, A, lda, B, ldb, &beta, C, ldc);
 }
 
 int chase_hip_gemm_z(chase_hip_ctx* c, char opA, int m, int n, int k, const double alpha[2], const void* A, long lda,
                      const void* B, long ldb, const double beta[2], void* C, long ldc)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "ctx == NULL");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (!alpha || !beta) return set_error(CHASE_HIP_EINVAL, "gemm_z: NULL alpha/beta");
     int rc = check_gemm(opA, m, n, k, A, lda, B, ldb, C, ldc);
     if (rc) return rc;
-    rc = c->ensure_ws((size_t)640 << 20);
-    if (rc) return rc;
-    int e = gemm_f64(c->stream, true, opA, m, n, k, alpha, (const double*)A, lda, (const double*)B, ldb, beta,
-                     (double*)C, ldc, (double*)c->ws, c->ws_bytes, c->num_cu, c->phase);
-    if (e) return hip_fail((hipError_t)e, "gemm_z launch");
+    return c->gemm(true, opA, m, n, k, alpha, (const double*)A, lda, (const double*)B, ldb, beta, (double*)C, ldc);
+}
+
+int chase_hip_gemm3m_enabled(void) { return gemm3m_enabled(); }
+int chase_hip_set_gemm3m(int on)
+{
+    gemm3m_set(on);
     return 0;
 }
 
-int chase_hip_gemm3m_enabled(void)
+int chase_hip_ctx_gemm_counters(chase_hip_ctx* c, int phase, double* flops_model, double* flops_executed,
+                                unsigned long long* calls, int reset)
 {
-    const char* e = getenv("CHASE_HIP_GEMM3M");
-    return (e ? atoi(e) != 0 : 1) ? 1 : 0;
+    if (!c || phase < 0 || phase > 2) return set_error(CHASE_HIP_EINVAL, "gemm_counters: bad argument");
+    if (flops_model) *flops_model = c->flops_model[phase];
+    if (flops_executed) *flops_executed = c->flops_exec[phase];
+    if (calls) *calls = c->gemm_calls[phase];
+    if (reset) { c->flops_model[phase] = c->flops_exec[phase] = 0; c->gemm_calls[phase] = 0; }
+    return 0;
 }
 
 int chase_hip_mfma_f64_peak(chase_hip_ctx* c, double* tflops)
 {
     if (!c || !tflops) return set_error(CHASE_HIP_EINVAL, "mfma_peak: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     const int blocks = c->num_cu * 2, iters = 16384;           // ~7 ms at peak: long enough for the clock to settle
     double* out = nullptr;
     HIPCHK(hipMalloc((void**)&out, (size_t)blocks * 256 * sizeof(double)));
@@ -247,6 +262,7 @@ int chase_hip_mfma_f64_peak(chase_hip_ctx* c, double* tflops)
 int chase_hip_hbm_copy_peak(chase_hip_ctx* c, size_t bytes, double* gbps)
 {
     if (!c || !gbps) return set_error(CHASE_HIP_EINVAL, "hbm_copy_peak: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     bytes &= ~(size_t)4095;
     if (bytes < 4096) return set_error(CHASE_HIP_EINVAL, "hbm_copy_peak: size too small");
     char *a = nullptr, *b = nullptr;

@@ -13,6 +13,10 @@ struct chase_hip_ctx {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int phase = 0;               // 1 between FilterPhaseStart/End: selects the filter-tagged GEMM symbol
+    // GEMM accounting per phase (0 other, 1 filter, 2 H-times-block outside the filter): flops of the reference's model
+    // (2*F*m*n*k, F = 4 complex) and flops the matrix cores executed (3/4 of it for three-multiplication launches)
+    double flops_model[3] = {0, 0, 0}, flops_exec[3] = {0, 0, 0};
+    unsigned long long gemm_calls[3] = {0, 0, 0};
     void* ws = nullptr;          // split-K slabs, grown on demand
     size_t ws_bytes = 0;
     enum { BUF_TINV = 0, BUF_PANEL, BUF_SCAL, BUF_LAMBDA, NBUF };
@@ -24,6 +28,9 @@ struct chase_hip_ctx {
     int ensure_ws(size_t bytes);
     int ensure_buf(int idx, size_t bytes);
     int ensure_hstage(size_t bytes);
+    // one GEMM through the MFMA kernel on this context's stream: sizes the split-K workspace for the shape, keeps the books
+    int gemm(bool cplx, char opA, int m, int n, int k, const double* alpha, const double* A, long lda, const double* B,
+             long ldb, const double* beta, double* C, long ldc);
 };
 
 namespace chase_hip {

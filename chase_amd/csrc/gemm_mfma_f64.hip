@@ -35,6 +35,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include "kernels.h"
 
 namespace chase_hip {
@@ -613,10 +615,41 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(const double* __restri
     }
 }
 
+// three-multiplication scheme for the complex filter products: -1 = not decided yet (CHASE_HIP_GEMM3M, default on)
+static std::atomic<int> g_gemm3m{-1};
+int gemm3m_enabled()
+{
+    int v = g_gemm3m.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("CHASE_HIP_GEMM3M");
+        v = (e ? atoi(e) != 0 : true) ? 1 : 0;
+        g_gemm3m.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+void gemm3m_set(int on) { g_gemm3m.store(on ? 1 : 0, std::memory_order_relaxed); }
+
+// split-K factor of the tail tiles (see GemmArgs): minimises rounds of the chip, capped by the slabs the workspace holds
+static int choose_tail_sk(long tail, long slots, int nkt, size_t slab_bytes, size_t ws_bytes)
+{
+    if (tail <= 0 || nkt < 16) return 1;
+    const int sk_max = (int)std::min<long>(std::min<long>(64, nkt / 8), (long)(ws_bytes / (slab_bytes * (size_t)tail)));
+    int sk = 1;
+    double best = 1e30;
+    for (int c = 1; c <= sk_max; ++c) {
+        const double rounds = (double)((tail * c + slots - 1) / slots) / c + 0.004 * c;
+        if (rounds < best - 1e-12) { best = rounds; sk = c; }
+    }
+    return sk;
+}
+
+struct LaunchInfo { int device; double* exec_flops; };     // per-device attribute flags, executed-flop accounting
+constexpr int MAX_DEVICES = 64;
+
 template <bool CPLX, bool OPA_C, int TAG>
 static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* alpha, const double* A, long lda,
                             const double* B, long ldb, const double* beta, double* C, long ldc,
-                            double* ws, size_t ws_bytes, int num_cu, bool allow3m)
+                            double* ws, size_t ws_bytes, int num_cu, bool allow3m, const LaunchInfo& li)
 {
     using C_ = Cfg<CPLX, OPA_C>;
     if (m <= 0 || n <= 0) return 0;
@@ -632,14 +665,12 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
     long tail = tiles - full;
     int sk = 1;
     const size_t slab_bytes = (size_t)C_::BM * C_::BN * sizeof(double) * C_::EPT;
-    if (tail > 0 && ws != nullptr && nkt >= 16) {
-        // cost of the tail in units of "one tile on one slot": ceil(tail*sk/slots)/sk rounds, slightly penalising big sk
-        const int sk_max = (int)std::min<long>(std::min<long>(64, nkt / 8), (long)(ws_bytes / (slab_bytes * (size_t)tail)));
-        double best = 1e30;
-        for (int c = 1; c <= sk_max; ++c) {
-            const double rounds = (double)((tail * c + slots - 1) / slots) / c + 0.004 * c;
-            if (rounds < best - 1e-12) { best = rounds; sk = c; }
-        }
+    // cost of the tail in units of "one tile on one slot": ceil(tail*sk/slots)/sk rounds, slightly penalising big sk
+    // (chosen against the fixed workspace cap, so the split - and with it the summation order - of a given shape does not
+    // depend on how far the caller's workspace happens to have grown; callers size it with gemm_f64_ws_need)
+    if (tail > 0 && ws != nullptr) {
+        sk = choose_tail_sk(tail, slots, nkt, slab_bytes, GEMM_WS_CAP);
+        if (slab_bytes * (size_t)tail * sk > ws_bytes) sk = choose_tail_sk(tail, slots, nkt, slab_bytes, ws_bytes);
     }
     if (sk <= 1) { full = tiles; tail = 0; sk = 1; }         // nothing to split: every tile is a whole tile
     int kchunk = ((nkt + sk - 1) / sk) * C_::BK;
@@ -651,24 +682,28 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
     const size_t lds_bytes = (size_t)C_::STAGES * C_::STAGE_UNITS * sizeof(d2_t);
     // ragged: some 16-column group of the last column tile lies entirely past n
     const bool ragged = (a.gn * C_::BN - n) >= 16;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the dynamic-LDS limit is a per-device function attribute: one flag per device (setting it twice is harmless, so a
+    // relaxed atomic is enough for concurrent first calls)
+    const int dev = (li.device >= 0 && li.device < MAX_DEVICES) ? li.device : 0;
+    static std::atomic<bool> attr_set[MAX_DEVICES];
+    if (!attr_set[dev].load(std::memory_order_relaxed)) {
         (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set = true;
+        attr_set[dev].store(true, std::memory_order_relaxed);
     }
-    // complex HEMMs of the filter phase (tag 1) and the Rayleigh-Ritz / residual HEMMs (tag 2) run the 3-product scheme
-    // unless CHASE_HIP_GEMM3M=0; Gram products, back-transforms and everything small stay on four products (tag 0)
+    // complex HEMMs of the filter phase (tag 1) run the 3-product scheme unless CHASE_HIP_GEMM3M=0 / gemm3m_set(0);
+    // everything else - Rayleigh-Ritz and residual products (the convergence test), Gram products, back-transforms -
+    // stays on four products like the reference's zgemm (CHASE_HIP_GEMM3M_RR=1 opts the tag-2 H-times-block products in)
     constexpr bool CAN3M = CPLX;
-    static const bool want3m = [] { const char* e = getenv("CHASE_HIP_GEMM3M"); return e ? atoi(e) != 0 : true; }();
+    const bool want3m = gemm3m_enabled() != 0;
     // the 3M instantiation has no register-staged fallback: whole row tiles, whole K tiles, 16-byte addressable operands
     const bool ok3m = allow3m && want3m && a.glds_ok && (m % C_::BM == 0) && (k % C_::BK == 0) && (kchunk % C_::BK == 0);
     if constexpr (CAN3M) {
-        static bool attr3 = false;
-        if (!attr3) {
+        static std::atomic<bool> attr3[MAX_DEVICES];
+        if (!attr3[dev].load(std::memory_order_relaxed)) {
             (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, false, CAN3M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, true, CAN3M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            attr3 = true;
+            attr3[dev].store(true, std::memory_order_relaxed);
         }
         if (ok3m) {
             if (ragged) hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG, true, CAN3M>), dim3(grid), dim3(256), lds_bytes, st, a);
@@ -683,6 +718,8 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
         hipLaunchKernelGGL((tail_reduce_kernel<CPLX, C_::BM, C_::BN>), dim3((unsigned)tail * TAIL_PARTS), dim3(256), 0, st, ws,
                            (int)full, sk, a.gn, m, n, C, ldc, a.alpha_re, a.alpha_im, a.beta_re, a.beta_im);
     }
+    // flops the matrix cores execute for this product: the reference's model 2*F*m*n*k (F = 4 complex), 3/4 of it in 3M
+    if (li.exec_flops) *li.exec_flops += 2.0 * (CPLX ? 4.0 : 1.0) * m * (double)n * k * ((CAN3M && ok3m) ? 0.75 : 1.0);
     return (int)hipGetLastError();
 }
 
@@ -693,7 +730,7 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
 template <bool CPLX, bool OPA_C, int TAG>
 static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha, const double* A, long lda,
                        const double* B, long ldb, const double* beta, double* C, long ldc,
-                       double* ws, size_t ws_bytes, int num_cu, bool allow3m)
+                       double* ws, size_t ws_bytes, int num_cu, bool allow3m, const LaunchInfo& li)
 {
     using C_ = Cfg<CPLX, OPA_C>;
     constexpr int EPT = C_::EPT;
@@ -701,22 +738,55 @@ static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha,
     const bool balanced = (C_::WAVES_N == 1);          // all waves span the tile width: skipped groups cost nobody
     if (balanced && n > C_::BN && rem != 0 && rem <= C_::BN - 16 && ws != nullptr) {
         const int n1 = n - rem;
-        int rc = launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n1, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, allow3m);
+        int rc = launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n1, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, allow3m, li);
         if (rc) return rc;
         return launch_gemm_part<CPLX, OPA_C, TAG>(st, m, rem, k, alpha, A, lda, B + (long)n1 * ldb * EPT, ldb, beta,
-                                                  C + (long)n1 * ldc * EPT, ldc, ws, ws_bytes, num_cu, allow3m);
+                                                  C + (long)n1 * ldc * EPT, ldc, ws, ws_bytes, num_cu, allow3m, li);
     }
-    return launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, allow3m);
+    return launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, allow3m, li);
+}
+
+// bytes of split-K workspace this product can use (0: none): the slabs of the tail tiles at the split that minimises the
+// rounds of the chip (the ragged-column launch is K-split over the whole chip); the caller grows its workspace to this
+// on demand instead of holding a fixed allocation
+template <bool CPLX, bool OPA_C>
+static size_t ws_need(int m, int n, int k, int num_cu)
+{
+    using C_ = Cfg<CPLX, OPA_C>;
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    const size_t slab_bytes = (size_t)C_::BM * C_::BN * sizeof(double) * C_::EPT;
+    const long slots = 2L * num_cu;
+    const int nkt = (k + C_::BK - 1) / C_::BK;
+    auto part = [&](int nn) -> size_t {
+        const long tiles = (long)((m + C_::BM - 1) / C_::BM) * ((nn + C_::BN - 1) / C_::BN);
+        const long tail = tiles % slots;
+        if (tail == 0) return 0;
+        const int sk = choose_tail_sk(tail, slots, nkt, slab_bytes, GEMM_WS_CAP);
+        return sk > 1 ? slab_bytes * (size_t)tail * sk : 0;
+    };
+    const int rem = n % C_::BN;
+    if (n > C_::BN && rem != 0 && rem <= C_::BN - 16) return std::max(part(n - rem), part(rem));
+    return part(n);
+}
+
+size_t gemm_f64_ws_need(bool cplx, char opA, int m, int n, int k, int num_cu)
+{
+    const bool opc = (opA == 'C' || opA == 'c' || opA == 'T' || opA == 't');
+    if (!cplx) return opc ? ws_need<false, true>(m, n, k, num_cu) : ws_need<false, false>(m, n, k, num_cu);
+    return opc ? ws_need<true, true>(m, n, k, num_cu) : ws_need<true, false>(m, n, k, num_cu);
 }
 
 int gemm_f64(hipStream_t st, bool cplx, char opA, int m, int n, int k, const double* alpha, const double* A, long lda,
              const double* B, long ldb, const double* beta, double* C, long ldc, double* ws, size_t ws_bytes, int num_cu,
-             int tag)
+             int tag, int device, double* exec_flops)
 {
     const bool opc = (opA == 'C' || opA == 'c' || opA == 'T' || opA == 't');
+    const LaunchInfo li{device, exec_flops};
+    static const bool rr3m = [] { const char* e = getenv("CHASE_HIP_GEMM3M_RR"); return e && atoi(e) != 0; }();
+    const bool allow2 = (tag == 2) && rr3m;
 #define CHASE_GEMM_DISPATCH(CP, OC)                                                                                    \
-    (tag == 1 ? launch_gemm<CP, OC, 1>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, true)   \
-              : launch_gemm<CP, OC, 0>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, tag == 2))
+    (tag == 1 ? launch_gemm<CP, OC, 1>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, true, li) \
+              : launch_gemm<CP, OC, 0>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, allow2, li))
     if (!cplx) return opc ? CHASE_GEMM_DISPATCH(false, true) : CHASE_GEMM_DISPATCH(false, false);
     return opc ? CHASE_GEMM_DISPATCH(true, true) : CHASE_GEMM_DISPATCH(true, false);
 #undef CHASE_GEMM_DISPATCH

@@ -3,6 +3,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <cmath>
+#include <utility>
 #include "grid.h"
 #include "kernels.h"
 
@@ -42,6 +45,41 @@ static int grid_common(chase_hip_grid* g, chase_hip_ctx* ctx, int nprow, int npc
     return 0;
 }
 
+int chase_hip_grid::wait_on(hipEvent_t e)
+{
+    hipStream_t cs = ctx->stream;
+    if (!profiling) {
+        HIPCHK(hipStreamWaitEvent(cs, e, 0));
+        return 0;
+    }
+    hipEvent_t a = nullptr, b = nullptr;
+    for (hipEvent_t* p : {&a, &b}) {
+        if (!ev_pool.empty()) { *p = ev_pool.back(); ev_pool.pop_back(); }
+        else HIPCHK(hipEventCreate(p));
+    }
+    HIPCHK(hipEventRecord(a, cs));
+    HIPCHK(hipStreamWaitEvent(cs, e, 0));
+    HIPCHK(hipEventRecord(b, cs));
+    ev_pending.emplace_back(a, b);
+    ++waits;
+    if (ev_pending.size() >= 8192) return collect_exposed();
+    return 0;
+}
+
+int chase_hip_grid::collect_exposed()
+{
+    if (ev_pending.empty()) return 0;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (auto& pr : ev_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess && ms > 0) exposed_ms += ms;
+        ev_pool.push_back(pr.first);
+        ev_pool.push_back(pr.second);
+    }
+    ev_pending.clear();
+    return 0;
+}
+
 extern "C" {
 
 int chase_hip_rccl_unique_id(char id[CHASE_HIP_UNIQUE_ID_BYTES])
@@ -59,27 +97,37 @@ int chase_hip_grid_create_rccl(chase_hip_grid** out, chase_hip_ctx* ctx, int npr
     if (!out) return set_error(CHASE_HIP_EINVAL, "grid_create: NULL out");
     chase_hip_grid* g = new chase_hip_grid();
     int rc = grid_common(g, ctx, nprow, npcol, rank);
-    if (rc) { delete g; return rc; }
+    if (rc) { chase_hip_grid_destroy(g); return rc; }
     g->use_rccl = true;
     g->force = getenv("CHASE_HIP_RCCL_FORCE") != nullptr;
     // the reference creates its row and column NCCL communicators the same way: one unique id per sub-communicator,
     // ncclCommInitRank on each (grid/mpiGrid2D.hpp:448-484)
-    if (npcol > 1 || g->force) {
-        if (!id_row) { delete g; return set_error(CHASE_HIP_EINVAL, "grid_create: row id missing"); }
-        ncclUniqueId u; memcpy(&u, id_row, sizeof u);
-        NCCLCHK(ncclCommInitRank(&g->comm[CHASE_HIP_ROW], npcol, u, g->mycol));
+    // every failure below releases what was created so far (partially initialised communicators are aborted)
+    rc = [&]() -> int {
+        if (npcol > 1 || g->force) {
+            if (!id_row) return set_error(CHASE_HIP_EINVAL, "grid_create: row id missing");
+            ncclUniqueId u; memcpy(&u, id_row, sizeof u);
+            NCCLCHK(ncclCommInitRank(&g->comm[CHASE_HIP_ROW], npcol, u, g->mycol));
+        }
+        if (nprow > 1 || g->force) {
+            if (!id_col) return set_error(CHASE_HIP_EINVAL, "grid_create: col id missing");
+            ncclUniqueId u; memcpy(&u, id_col, sizeof u);
+            NCCLCHK(ncclCommInitRank(&g->comm[CHASE_HIP_COL], nprow, u, g->myrow));
+        }
+        // first collective on a communicator sets up the xGMI connections (hundreds of ms): pay it here, not in the first
+        // filter step, and surface transport problems at construction
+        HIPCHK(hipMemsetAsync(g->scal_dev, 0, 64, g->comm_stream));
+        for (int grp = 0; grp < 2; ++grp)
+            if (g->comm[grp]) NCCLCHK(ncclAllReduce(g->scal_dev, g->scal_dev, 8, ncclDouble, ncclSum, g->comm[grp], g->comm_stream));
+        HIPCHK(hipStreamSynchronize(g->comm_stream));
+        return 0;
+    }();
+    if (rc) {
+        for (int i = 0; i < 2; ++i)
+            if (g->comm[i]) { ncclCommAbort(g->comm[i]); g->comm[i] = nullptr; }
+        chase_hip_grid_destroy(g);
+        return rc;
     }
-    if (nprow > 1 || g->force) {
-        if (!id_col) { delete g; return set_error(CHASE_HIP_EINVAL, "grid_create: col id missing"); }
-        ncclUniqueId u; memcpy(&u, id_col, sizeof u);
-        NCCLCHK(ncclCommInitRank(&g->comm[CHASE_HIP_COL], nprow, u, g->myrow));
-    }
-    // first collective on a communicator sets up the xGMI connections (hundreds of ms): pay it here, not in the first
-    // filter step, and surface transport problems at construction
-    HIPCHK(hipMemsetAsync(g->scal_dev, 0, 64, g->comm_stream));
-    for (int grp = 0; grp < 2; ++grp)
-        if (g->comm[grp]) NCCLCHK(ncclAllReduce(g->scal_dev, g->scal_dev, 8, ncclDouble, ncclSum, g->comm[grp], g->comm_stream));
-    HIPCHK(hipStreamSynchronize(g->comm_stream));
     *out = g;
     return 0;
 }
@@ -91,7 +139,7 @@ int chase_hip_grid_create_host(chase_hip_grid** out, chase_hip_ctx* ctx, int npr
     if (nprow * npcol > 1 && (!allreduce || !bcast)) return set_error(CHASE_HIP_EINVAL, "grid_create: NULL callback");
     chase_hip_grid* g = new chase_hip_grid();
     int rc = grid_common(g, ctx, nprow, npcol, rank);
-    if (rc) { delete g; return rc; }
+    if (rc) { chase_hip_grid_destroy(g); return rc; }
     g->use_rccl = false;
     g->h_allreduce = allreduce; g->h_bcast = bcast; g->h_user = user;
     *out = g;
@@ -101,16 +149,18 @@ int chase_hip_grid_create_host(chase_hip_grid** out, chase_hip_ctx* ctx, int npr
 int chase_hip_grid_destroy(chase_hip_grid* g)
 {
     if (!g) return 0;
-    hipSetDevice(g->ctx->device);
-    hipStreamSynchronize(g->comm_stream);
+    if (g->ctx) hipSetDevice(g->ctx->device);
+    if (g->comm_stream) hipStreamSynchronize(g->comm_stream);
     for (int i = 0; i < 2; ++i)
         if (g->comm[i]) ncclCommDestroy(g->comm[i]);
-    hipFree(g->scal_dev);
+    if (g->scal_dev) hipFree(g->scal_dev);
     for (hipEvent_t e : g->slots)
         if (e) hipEventDestroy(e);
-    hipEventDestroy(g->ev_compute);
-    hipEventDestroy(g->ev_comm);
-    hipStreamDestroy(g->comm_stream);
+    for (auto& pr : g->ev_pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (hipEvent_t e : g->ev_pool) hipEventDestroy(e);
+    if (g->ev_compute) hipEventDestroy(g->ev_compute);
+    if (g->ev_comm) hipEventDestroy(g->ev_comm);
+    if (g->comm_stream) hipStreamDestroy(g->comm_stream);
     delete g;
     return 0;
 }
@@ -175,8 +225,7 @@ int chase_hip_grid_wait(chase_hip_grid* g)
     if (!g) return set_error(CHASE_HIP_EINVAL, "grid_wait: NULL grid");
     if (!g->use_rccl) return 0;
     HIPCHK(hipEventRecord(g->ev_comm, g->comm_stream));
-    HIPCHK(hipStreamWaitEvent(g->ctx->stream, g->ev_comm, 0));
-    return 0;
+    return g->wait_on(g->ev_comm);
 }
 
 /* slot events: record = "everything issued so far on the communication stream"; wait = the context (compute) stream waits
@@ -194,28 +243,114 @@ int chase_hip_grid_event_wait(chase_hip_grid* g, int slot)
 {
     if (!g || slot < 0) return set_error(CHASE_HIP_EINVAL, "event_wait: bad argument");
     if (!g->use_rccl || slot >= (int)g->slots.size() || !g->slots[slot]) return 0;
-    HIPCHK(hipStreamWaitEvent(g->ctx->stream, g->slots[slot], 0));
-    return 0;
+    return g->wait_on(g->slots[slot]);
 }
 
 int chase_hip_grid_agree_max(chase_hip_grid* g, int* value)
 {
     if (!g || !value) return set_error(CHASE_HIP_EINVAL, "agree_max: NULL argument");
     if (g->nprow * g->npcol == 1 && !g->force) return 0;
-    // max over all ranks = max over rows of (max over columns); implemented with SUM all-reduces of one-hot-free
-    // encoding is not possible, so use two passes of allreduce on (value) via the identity max(a,b) for
-    // non-negative ints: we all-reduce the SUM of indicator(value > 0) and of value; control flow only needs
-    // "did anybody fail", and the failing info itself for reporting.
-    double v[2] = {(double)(*value != 0 ? 1 : 0), (double)*value};
+    // exact maximum with SUM all-reduces (the one reduction both transports offer): every member of a group writes its
+    // value into its own slot of a zeroed vector, the sum is then the list of all values.  Row groups first, column
+    // groups on the row maxima second.
     chase_hip_ctx* c = g->ctx;
-    HIPCHK(hipMemcpyAsync(g->scal_dev, v, sizeof v, hipMemcpyHostToDevice, c->stream));
-    int rc = chase_hip_grid_allreduce(g, CHASE_HIP_ROW, g->scal_dev, 2, 0);
+    int cur = *value;
+    for (int grp : {CHASE_HIP_ROW, CHASE_HIP_COL}) {
+        if (!g->active(grp)) continue;
+        const int sz = g->group_size(grp);
+        if (sz > 8) return set_error(CHASE_HIP_EINVAL, "agree_max: group larger than the scratch (8)");
+        double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        v[g->group_rank(grp)] = (double)cur;
+        HIPCHK(hipMemcpyAsync(g->scal_dev, v, sizeof v, hipMemcpyHostToDevice, c->stream));
+        int rc = chase_hip_grid_allreduce(g, grp, g->scal_dev, 8, 0);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(v, g->scal_dev, sizeof v, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < sz; ++i) cur = std::max(cur, (int)std::lround(v[i]));
+    }
+    *value = cur;
+    return 0;
+}
+
+/* point-to-point exchange inside a group (grid/nccl_utils.hpp:271 ncclSendrecvWrapper): send sendcount doubles to group
+ * member peer_send and receive recvcount doubles from peer_recv (a negative peer skips that half; peer == own group rank
+ * copies locally).  Ordered after the work enqueued on the context stream; the context stream waits for the result. */
+int chase_hip_grid_sendrecv(chase_hip_grid* g, int group, const void* sendbuf, size_t sendcount, int peer_send,
+                            void* recvbuf, size_t recvcount, int peer_recv)
+{
+    if (!g) return set_error(CHASE_HIP_EINVAL, "sendrecv: NULL grid");
+    if (group != CHASE_HIP_ROW && group != CHASE_HIP_COL) return set_error(CHASE_HIP_EINVAL, "sendrecv: bad group");
+    const int sz = g->group_size(group), me = g->group_rank(group);
+    if (peer_send >= sz || peer_recv >= sz) return set_error(CHASE_HIP_EINVAL, "sendrecv: peer outside the group");
+    if (sendcount == 0) peer_send = -1;
+    if (recvcount == 0) peer_recv = -1;
+    chase_hip_ctx* c = g->ctx;
+    if (peer_send == me && peer_recv == me) {
+        if (sendcount != recvcount) return set_error(CHASE_HIP_EINVAL, "sendrecv: self exchange with different counts");
+        HIPCHK(hipMemcpyAsync(recvbuf, sendbuf, sendcount * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        return 0;
+    }
+    if (peer_send == me || peer_recv == me) return set_error(CHASE_HIP_EINVAL, "sendrecv: half of a self exchange");
+    if (peer_send < 0 && peer_recv < 0) return 0;
+    if (g->use_rccl) {
+        if (!g->comm[group]) return set_error(CHASE_HIP_ECOMM, "sendrecv: group has no communicator");
+        HIPCHK(hipEventRecord(g->ev_compute, c->stream));
+        HIPCHK(hipStreamWaitEvent(g->comm_stream, g->ev_compute, 0));
+        NCCLCHK(ncclGroupStart());
+        if (peer_send >= 0) NCCLCHK(ncclSend(sendbuf, sendcount, ncclDouble, peer_send, g->comm[group], g->comm_stream));
+        if (peer_recv >= 0) NCCLCHK(ncclRecv(recvbuf, recvcount, ncclDouble, peer_recv, g->comm[group], g->comm_stream));
+        NCCLCHK(ncclGroupEnd());
+        return chase_hip_grid_wait(g);
+    }
+    if (!g->h_sendrecv) return set_error(CHASE_HIP_ECOMM, "sendrecv: host transport has no send/recv callback");
+    const size_t sb = (peer_send >= 0 ? sendcount : 0) * sizeof(double), rb = (peer_recv >= 0 ? recvcount : 0) * sizeof(double);
+    int rc = c->ensure_hstage(sb + rb + 16);
     if (rc) return rc;
-    rc = chase_hip_grid_allreduce(g, CHASE_HIP_COL, g->scal_dev, 2, 0);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(v, g->scal_dev, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    double* hs = (double*)c->hstage;
+    double* hr = hs + (sb / sizeof(double));
+    if (sb) HIPCHK(hipMemcpyAsync(hs, sendbuf, sb, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (v[0] > 0.5 && *value == 0) *value = (int)(v[1] / v[0] + 0.5) > 0 ? (int)(v[1] / v[0] + 0.5) : 1;
+    if (g->h_sendrecv(g->h_user, group, hs, sb / sizeof(double), peer_send, hr, rb / sizeof(double), peer_recv))
+        return set_error(CHASE_HIP_ECOMM, "host transport send/recv callback failed");
+    if (rb) HIPCHK(hipMemcpyAsync(recvbuf, hr, rb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int chase_hip_grid_set_host_sendrecv(chase_hip_grid* g, chase_hip_host_sendrecv_fn fn)
+{
+    if (!g) return set_error(CHASE_HIP_EINVAL, "set_host_sendrecv: NULL grid");
+    g->h_sendrecv = fn;
+    return 0;
+}
+
+int chase_hip_grid_set_profiling(chase_hip_grid* g, int on)
+{
+    if (!g) return set_error(CHASE_HIP_EINVAL, "set_profiling: NULL grid");
+    if (!on && g->profiling) { int rc = g->collect_exposed(); if (rc) return rc; }
+    g->profiling = on != 0 && g->use_rccl;
+    return 0;
+}
+int chase_hip_grid_comm_exposed_ms(chase_hip_grid* g, double* ms, unsigned long long* waits, int reset)
+{
+    if (!g) return set_error(CHASE_HIP_EINVAL, "comm_exposed_ms: NULL grid");
+    int rc = g->collect_exposed();
+    if (rc) return rc;
+    if (ms) *ms = g->exposed_ms;
+    if (waits) *waits = g->waits;
+    if (reset) { g->exposed_ms = 0; g->waits = 0; }
+    return 0;
+}
+int chase_hip_grid_transport(chase_hip_grid* g, int* is_rccl, int* row_ranks, int* col_ranks)
+{
+    if (!g) return set_error(CHASE_HIP_EINVAL, "grid_transport: NULL grid");
+    if (is_rccl) *is_rccl = g->use_rccl ? 1 : 0;
+    int n[2] = {1, 1};
+    for (int i = 0; i < 2; ++i) {
+        if (g->use_rccl && g->comm[i]) NCCLCHK(ncclCommCount(g->comm[i], &n[i]));
+        else if (!g->use_rccl) n[i] = g->group_size(i);
+    }
+    if (row_ranks) *row_ranks = n[CHASE_HIP_ROW];
+    if (col_ranks) *col_ranks = n[CHASE_HIP_COL];
     return 0;
 }
 

@@ -222,13 +222,13 @@ using namespace chase_hip;
 extern "C" int chase_hip_heevd_gpu(chase_hip_ctx* c, int cplx_, int n, void* A_, long lda, double* w_host)
 {
     if (!c || !A_ || !w_host) return set_error(CHASE_HIP_EINVAL, "heevd_gpu: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (n < 3 || lda < n) return set_error(CHASE_HIP_EINVAL, "heevd_gpu: need n >= 3 and lda >= n");
     const bool cplx = cplx_ != 0;
     const int E = cplx ? 2 : 1;
     double* A = (double*)A_;
     hipStream_t st = c->stream;
-    int rc = c->ensure_ws((size_t)640 << 20);
-    if (rc) return rc;
+    int rc = 0;
     const int nch_max = (n + TCW - 1) / TCW, nrb_max = (n + TRB - 1) / TRB;
     // scratch: vbuf, pbuf (n T each) | part (nch_max x n T) | dots | d, e (n) | tau (n T) | Z (n x n real) | Zc (n x n T)
     const size_t szv = (size_t)n * E, szpart = (size_t)nch_max * n * E, szZ = (size_t)n * n;

@@ -198,10 +198,11 @@ static int g3(chase_hip_ctx* c, bool cplx, char op, int m, int n, int k, double 
 {
     if (m <= 0 || n <= 0) return 0;
     const double alpha[2] = {ar, 0.0}, beta[2] = {br, 0.0};
-    int e = gemm_f64(c->stream, cplx, op, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, (double*)c->ws, c->ws_bytes,
-                     c->num_cu);
-    if (e) return hip_fail((hipError_t)e, "gemm launch");
-    return 0;
+    const int ph = c->phase;
+    c->phase = 0;
+    const int rc = c->gemm(cplx, op, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
+    c->phase = ph;
+    return rc;
 }
 
 namespace chase_hip {
@@ -245,6 +246,7 @@ int hh_apply_q_left(chase_hip_ctx* c, bool cplx, const double* Vstore, long ldv,
 extern "C" int chase_hip_houseqr(chase_hip_ctx* c, int cplx_, int m, int n, void* V_, long ldv)
 {
     if (!c || !V_) return set_error(CHASE_HIP_EINVAL, "houseqr: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (m < n || n < 0 || ldv < m) return set_error(CHASE_HIP_EINVAL, "houseqr: need m >= n and ldv >= m");
     if (n == 0) return 0;
     const bool cplx = cplx_ != 0;
@@ -252,7 +254,6 @@ extern "C" int chase_hip_houseqr(chase_hip_ctx* c, int cplx_, int m, int n, void
     double* A = (double*)V_;
     hipStream_t st = c->stream;
     const int npan = (n + HNB - 1) / HNB;
-    RC(c->ensure_ws((size_t)640 << 20));
     // one scratch block: Q (m x n) | Vb (m x nb) | W1, W2 (nb x n) | G (nb x nb) | T (npan x nb x nb) | tau (n)
     const size_t szQ = (size_t)m * n * E, szV = (size_t)m * HNB * E, szW = (size_t)HNB * n * E;
     const size_t szG = (size_t)HNB * HNB * E, szT = (size_t)npan * HNB * HNB * E, szTau = (size_t)n * E;

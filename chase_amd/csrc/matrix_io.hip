@@ -56,6 +56,7 @@ int chase_hip_load_matrix_shard(chase_hip_ctx* c, const char* path, int cplx, lo
                                 int pi, int nb, int pc, int pj, void* dev, long ldd)
 {
     if (!c || !path || (!dev && mloc > 0 && nloc > 0)) return set_error(CHASE_HIP_EINVAL, "load_matrix_shard: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (N <= 0 || mloc < 0 || nloc < 0 || mb <= 0 || nb <= 0 || pr <= 0 || pc <= 0 || pi < 0 || pi >= pr || pj < 0 ||
         pj >= pc || ldd < mloc)
         return set_error(CHASE_HIP_EINVAL, "load_matrix_shard: bad shape");
@@ -103,6 +104,7 @@ int chase_hip_load_matrix_shard(chase_hip_ctx* c, const char* path, int cplx, lo
 int chase_hip_save_matrix(chase_hip_ctx* c, const char* path, int cplx, int m, int n, const void* dev, long ldd)
 {
     if (!c || !path || (!dev && m > 0 && n > 0)) return set_error(CHASE_HIP_EINVAL, "save_matrix: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (m < 0 || n < 0 || ldd < m) return set_error(CHASE_HIP_EINVAL, "save_matrix: bad shape");
     const size_t es = cplx ? 16 : 8;
     Fd f;

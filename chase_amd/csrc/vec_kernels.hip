@@ -1,12 +1,32 @@
 // vec_kernels.hip — HBM-bound O(N*n) kernels of the ChASE hot path (wave64 shuffle reductions, 16-byte accesses)
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "kernels.h"
 #include "ctx.h"
 #include "../../include/chase_hip.h"
 
+int chase_hip_ctx::gemm(bool cplx, char opA, int m, int n, int k, const double* alpha, const double* A, long lda,
+                        const double* B, long ldb, const double* beta, double* C, long ldc)
+{
+    if (m <= 0 || n <= 0) return 0;
+    // workspace: what this shape's tail split can use (never the whole fixed cap up front), at least 8 MB so that the
+    // ragged-column launch is always available
+    const size_t need = std::max(chase_hip::gemm_f64_ws_need(cplx, opA, m, n, k, num_cu), (size_t)8 << 20);
+    int rc = ensure_ws((need + ((size_t)32 << 20) - 1) & ~(((size_t)32 << 20) - 1));
+    if (rc) return rc;
+    const int ph = (phase >= 0 && phase <= 2) ? phase : 0;
+    int e = chase_hip::gemm_f64(stream, cplx, opA, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, (double*)ws, ws_bytes,
+                                num_cu, phase, device, &flops_exec[ph]);
+    if (e) return chase_hip::hip_fail((hipError_t)e, "gemm launch");
+    flops_model[ph] += 2.0 * (cplx ? 4.0 : 1.0) * m * (double)n * k;
+    ++gemm_calls[ph];
+    return 0;
+}
+
 int chase_hip_ctx::ensure_ws(size_t bytes)
 {
     if (ws_bytes >= bytes) return 0;
+    (void)hipSetDevice(device);
     if (ws) { hipStreamSynchronize(stream); hipFree(ws); ws = nullptr; ws_bytes = 0; }
     hipError_t e = hipMalloc(&ws, bytes);
     if (e != hipSuccess) return chase_hip::set_error(CHASE_HIP_ENOMEM, "workspace allocation failed");
@@ -17,6 +37,7 @@ int chase_hip_ctx::ensure_ws(size_t bytes)
 int chase_hip_ctx::ensure_buf(int idx, size_t bytes)
 {
     if (buf_bytes[idx] >= bytes) return 0;
+    (void)hipSetDevice(device);
     if (bufs[idx]) { hipStreamSynchronize(stream); hipFree(bufs[idx]); bufs[idx] = nullptr; buf_bytes[idx] = 0; }
     hipError_t e = hipMalloc(&bufs[idx], bytes);
     if (e != hipSuccess) return chase_hip::set_error(CHASE_HIP_ENOMEM, "scratch allocation failed");
@@ -27,6 +48,7 @@ int chase_hip_ctx::ensure_buf(int idx, size_t bytes)
 int chase_hip_ctx::ensure_hstage(size_t bytes)
 {
     if (hstage_bytes >= bytes) return 0;
+    (void)hipSetDevice(device);
     if (hstage) { hipStreamSynchronize(stream); hipHostFree(hstage); hstage = nullptr; hstage_bytes = 0; }
     hipError_t e = hipHostMalloc(&hstage, bytes, hipHostMallocDefault);
     if (e != hipSuccess) return chase_hip::set_error(CHASE_HIP_ENOMEM, "pinned staging allocation failed");

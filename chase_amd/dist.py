@@ -20,6 +20,12 @@ _sig("chase_hip_grid_allreduce", c_int, c_void_p, c_int, c_void_p, c_size_t, c_i
 _sig("chase_hip_grid_bcast", c_int, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int)
 _sig("chase_hip_grid_wait", c_int, c_void_p)
 _sig("chase_hip_grid_agree_max", c_int, c_void_p, P(c_int))
+SR_FN = C.CFUNCTYPE(c_int, c_void_p, c_int, P(c_double), c_size_t, c_int, P(c_double), c_size_t, c_int)
+_sig("chase_hip_grid_sendrecv", c_int, c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_int)
+_sig("chase_hip_grid_set_host_sendrecv", c_int, c_void_p, SR_FN)
+_sig("chase_hip_grid_set_profiling", c_int, c_void_p, c_int)
+_sig("chase_hip_grid_comm_exposed_ms", c_int, c_void_p, P(c_double), P(C.c_ulonglong), c_int)
+_sig("chase_hip_grid_transport", c_int, c_void_p, P(c_int), P(c_int), P(c_int))
 for _n in ("chase_hip_block_len",):
     _sig(_n, c_long, c_long, c_int)
 _sig("chase_hip_numroc", c_long, c_long, c_long, c_int, c_int)
@@ -121,10 +127,50 @@ class Grid:
                     print("bcast callback failed:", e, flush=True)
                     return 1
 
-            self._cb = (AR_FN(_ar), BC_FN(_bc))          # keep the thunks alive
+            def _sr(user, group, sbuf, scount, peer_send, rbuf, rcount, peer_recv):
+                try:
+                    ranks = row_ranks if group == ROW else col_ranks
+                    ops = []
+                    if peer_send >= 0 and scount:
+                        ts = torch.from_numpy(np.ctypeslib.as_array(sbuf, shape=(scount,)))
+                        ops.append(dist.P2POp(dist.isend, ts, ranks[peer_send], group=groups[group]))
+                    if peer_recv >= 0 and rcount:
+                        tr = torch.from_numpy(np.ctypeslib.as_array(rbuf, shape=(rcount,)))
+                        ops.append(dist.P2POp(dist.irecv, tr, ranks[peer_recv], group=groups[group]))
+                    for w in (dist.batch_isend_irecv(ops) if ops else []):
+                        w.wait()
+                    return 0
+                except Exception as e:  # pragma: no cover
+                    print("sendrecv callback failed:", e, flush=True)
+                    return 1
+
+            self._cb = (AR_FN(_ar), BC_FN(_bc), SR_FN(_sr))          # keep the thunks alive
             check(lib.chase_hip_grid_create_host(C.byref(h), ctx.h, nprow, npcol, rank, self._cb[0], self._cb[1], None),
                   "grid_create_host")
+            check(lib.chase_hip_grid_set_host_sendrecv(h, self._cb[2]), "set_host_sendrecv")
         self.h = h
+
+    def set_profiling(self, on):
+        check(lib.chase_hip_grid_set_profiling(self.h, int(on)), "grid_set_profiling")
+
+    def comm_exposed_ms(self, reset=False):
+        """(milliseconds the compute stream spent waiting for collectives with nothing else to run, number of waits)"""
+        ms, n = c_double(), C.c_ulonglong()
+        check(lib.chase_hip_grid_comm_exposed_ms(self.h, C.byref(ms), C.byref(n), int(reset)), "comm_exposed_ms")
+        return ms.value, n.value
+
+    def transport_info(self):
+        """(is_rccl, ranks RCCL reports for the row communicator, for the column communicator)"""
+        a, r, c = c_int(), c_int(), c_int()
+        check(lib.chase_hip_grid_transport(self.h, C.byref(a), C.byref(r), C.byref(c)), "grid_transport")
+        return bool(a.value), r.value, c.value
+
+    def sendrecv(self, group, send, peer_send, recv, peer_recv):
+        """send / recv: DeviceArray (or None); counts in doubles are taken from the arrays"""
+        def cnt(a):
+            return 0 if a is None else int(np.prod(a.shape)) * (2 if a.dtype == np.complex128 else 1)
+        check(lib.chase_hip_grid_sendrecv(self.h, group, send.ptr if send is not None else None, cnt(send), peer_send,
+                                          recv.ptr if recv is not None else None, cnt(recv), peer_recv), "grid_sendrecv")
 
     def close(self):
         if self.h:
@@ -198,6 +244,10 @@ class DistSolver:
 
     def trace(self):
         return lib.chase_hip_solver_trace(self.h).decode().splitlines()
+
+    def set_iteration_hook(self, fn):
+        from .capi import set_iteration_hook
+        set_iteration_hook(self, fn)
 
     def local_V(self):
         out = np.empty((self.m_loc, self.ncol), dtype=self.dt, order="F")

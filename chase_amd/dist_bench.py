@@ -1,9 +1,14 @@
-"""bench.py --gpus N (N > 1): one process per GPU (torch.distributed.run), 2D block grid of the reference
-(nprow x npcol with nprow >= npcol: 2x1, 2x2, 4x2), RCCL row/column all-reduces over xGMI, strong scaling on the same
-workload as the single-GPU line.  torch.distributed (gloo over MASTER_ADDR) is used only for bootstrap, barriers and
-the max-over-ranks timing."""
+"""One rank of `bench.py --gpus N` (N > 1; also the 1x1-grid development runs): one process per GPU, 2D grid of the
+reference (nprow x npcol with nprow >= npcol: 2x1, 2x2, 4x2; grid/mpiGrid2D.hpp), RCCL row/column all-reduces over xGMI,
+the SAME workload as the single-GPU line (strong scaling).  torch.distributed (gloo over MASTER_ADDR) is used only for
+bootstrap (unique-id exchange), barriers and the max / sum over ranks of the timing figures.
+
+A rank whose communicator cannot be created exits non-zero: there is no fallback transport in a measured run (the
+host-callback transport exists for tests on a single-GPU box: CHASE_HIP_TRANSPORT=host, labelled in config.workload)."""
+import ctypes
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -12,7 +17,7 @@ import numpy as np
 def run_distributed(args):
     import torch
     import torch.distributed as dist
-    from .capi import Context
+    from .capi import Context, gemm_counters
     from . import dist as cd
     import bench as B
 
@@ -20,38 +25,39 @@ def run_distributed(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     dist.init_process_group("gloo")
-    workload = args.workload or B.DEFAULT_BY_GPUS.get(world, B.DEFAULT_WORKLOAD)
+    workload = args.workload or B.DEFAULT_WORKLOAD
     N, cplx, nev, nex = B.WORKLOADS[workload]
     if args.n:
         N = args.n
+    nevex = nev + nex
     nprow, npcol = cd.grid_shape(world)
     myrow, mycol = cd.coords_of(rank, nprow)
-    ndev = torch.cuda.device_count()
-    ctx = Context(local_rank % max(ndev, 1))
-    pg = cd.make_process_groups(nprow, npcol)
     transport = os.environ.get("CHASE_HIP_TRANSPORT", "rccl")
-    grid, err = None, ""
+    # health check BEFORE anybody enters ncclCommInitRank (which blocks until all members arrive): every rank must have
+    # its device context; a rank without one makes ALL ranks leave with an error instead of leaving the others hanging
+    ctx, err = None, ""
     try:
-        grid = cd.Grid(ctx, nprow, npcol, rank, transport=transport, pg=pg)
-    except Exception as e:  # communicator creation failed on this rank
+        ndev = torch.cuda.device_count()
+        ctx = Context(local_rank % max(ndev, 1))
+    except Exception as e:
         err = str(e)
-    # every rank must take the same transport: agree on success, fall back together (numbers measured through the host
-    # transport are labelled as such in config.workload - they are a functional fallback, not the RCCL path)
-    okflag = torch.tensor([1 if grid is not None else 0], dtype=torch.int32)
+    okflag = torch.tensor([1 if ctx is not None else 0], dtype=torch.int32)
     dist.all_reduce(okflag, op=dist.ReduceOp.MIN)
     if int(okflag[0]) == 0:
-        if grid is not None:
-            grid.close()
-        if transport != "rccl":
-            raise RuntimeError("grid creation failed: " + err)
-        if rank == 0:
-            import sys
-            print("bench: RCCL grid creation failed (%s); falling back to the host-callback transport" % err, file=sys.stderr)
-        transport = "host"
+        print(f"bench rank {rank}: no usable device context ({err or 'another rank failed'})", file=sys.stderr, flush=True)
+        dist.destroy_process_group()
+        sys.exit(3)
+    pg = cd.make_process_groups(nprow, npcol)
+    try:
         grid = cd.Grid(ctx, nprow, npcol, rank, transport=transport, pg=pg)
+    except Exception as e:
+        # no silent fallback: a run that would measure PCIe + gloo instead of RCCL over xGMI must not print a value
+        print(f"bench rank {rank}: {transport} grid creation failed: {e}", file=sys.stderr, flush=True)
+        os._exit(4)
+    is_rccl, rccl_row, rccl_col = grid.transport_info()
+    grid.set_profiling(True)
     # RCCL prints a version banner through C stdio at communicator creation; push it out NOW on every rank so that the
     # JSON line rank 0 prints at the end is the last line of the job's stdout
-    import ctypes
     ctypes.CDLL(None).fflush(None)
     mb = nb = args.block_cyclic if args.block_cyclic >= 0 else B.DEFAULT_BLOCK_CYCLIC.get(workload, 0)
     rl, cl = cd.Layout(N, mb, nprow), cd.Layout(N, nb, npcol)
@@ -66,72 +72,73 @@ def run_distributed(args):
         ctx.sync()
         s = cd.DistSolver(ctx, grid, dH, N, nev, nex, cplx, mb, nb)
         s.set(device_rng=1)
-    F = 4 if cplx else 1
-    for _ in range(args.warmup):
-        s.set(reset_counters=1)
-        s.solve()
-    ctx.sync()
-    dist.barrier()
-    t0 = time.perf_counter()
-    stats = []
-    for _ in range(args.steps):
-        s.set(reset_counters=1)
-        st = s.solve()
-        st["hemm_calls"] = s.get("hemm_calls")
-        st["hemm_reused_vecs"] = s.get("hemm_reused_vecs")
-        stats.append(st)
-    ctx.sync()
-    dist.barrier()
-    wall = time.perf_counter() - t0
-    # MAX over ranks of the wall time and of the filter time
-    t = torch.tensor([wall, sum(x["filter_ms_device"] for x in stats) * 1e-3], dtype=torch.float64)
+
+    def snapshot():
+        model, execd, calls = gemm_counters(ctx, 1)
+        exposed_ms, waits = grid.comm_exposed_ms()
+        return {"filter_ms": s.get("filter_ms"), "hemm_calls": s.get("hemm_calls"), "reused": s.get("hemm_reused_vecs"),
+                "model": model, "exec": execd, "gemms": calls, "exposed_ms": exposed_ms, "waits": waits}
+
+    timer = B.StepTimer(args.steps, args.warmup, ctx.sync, dist.barrier, snapshot)
+    complete, last = B.run_timed_solves(s, timer, nev, lambda: (s.ritzv[:nev].copy(), s.resid()[:nev].copy()))
+    wall_loc = timer.t1 - timer.t0
+    # MAX over ranks of the wall time, the filter time and the exposed communication; SUM of the kernel-side flop books
+    t = torch.tensor([wall_loc, timer.diff("filter_ms") * 1e-3, timer.diff("exposed_ms")], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall, filt_s = float(t[0]), float(t[1])
-    # vectors that went through a filter HEMM (first-step columns served from the Rayleigh-Ritz products are not credited)
-    reused = sum(x["hemm_reused_vecs"] for x in stats)
-    vecs = sum(x["filtered_vecs"] for x in stats) - reused
-    calls = sum(x["hemm_calls"] for x in stats)
-    flops = 2.0 * F * N * N * vecs                      # whole-job FLOPs (all GPUs), reference model
-    gflops = flops / filt_s / 1e9
-    m_loc, n_loc = rl.count(myrow), cl.count(mycol)
-    xf = B.mfma_executed_fraction(cplx, m_loc, n_loc) if (m_loc % 128 == 0 and n_loc % 128 == 0) else 1.0
-    resid = s.resid()[:nev]
-    spec = None if pseudo else B.spectrum_check(s.ritzv[:nev], N, nev)
-    ok = bool(np.max(resid) < 1e-8 and stats[-1]["locked"] >= nev and (spec is None or spec["ok"]))
-    last = stats[-1]
+    wall, filt_s, exposed_ms = float(t[0]), float(t[1]), float(t[2])
+    f = torch.tensor([timer.diff("model"), timer.diff("exec")], dtype=torch.float64)
+    dist.all_reduce(f, op=dist.ReduceOp.SUM)
+    model_flops, exec_flops = float(f[0]), float(f[1])
+    calls = int(timer.diff("hemm_calls"))
+    reused = int(timer.diff("reused"))
+    hemm_vecs = timer.filtered_timed - reused
+    F = 4 if cplx else 1
+    if not pseudo:
+        formula = 2.0 * F * N * N * hemm_vecs                 # whole-job flops of the reference's model
+        assert abs(model_flops - formula) <= 1e-9 * formula, (model_flops, formula)
+    gflops = model_flops / filt_s / 1e9
+    lam, resid = last
+    spec = None if pseudo else B.spectrum_check(lam, N, nev)
+    ok = bool(np.max(resid) < 1e-8 and (spec is None or spec["ok"]))
+    st = complete[-1]
+    solve_s = float(np.mean([c["t_all"] for c in complete]))
     out = None
     if rank == 0:
         out = {
             "metric": "chebyshev_filter_hemm_gflops", "value": gflops, "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if args.workload else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "complex f64" if cplx else "f64", "data": "synthetic",
             "config": {"workload": f"{workload}: ChASE solve, "
                                    + ("synthetic Bethe-Salpeter pseudo-Hermitian (Solve_pseudo, H^2 filter)" if pseudo
                                       else "perturbed Clement-type Hermitian (x100/N)") + f" N={N} "
                                    f"{'complex' if cplx else 'real'} fp64, nev={nev} nex={nex}, tol 1e-10, deg 20 opt, "
                                    f"{nprow}x{npcol} {'block-cyclic nb=%d' % nb if nb else 'block'} grid, "
-                                   + ("RCCL" if transport == "rccl" else "host-callback (gloo) transport"),
-                       "N": N, "nev": nev, "nex": nex, "grid": f"{nprow}x{npcol}"},
-            "eigenpairs_per_sec": nev / (wall / args.steps),
-            "pct_fp64_mfma_peak": 100.0 * xf * gflops / 1e3 / world / B.FP64_MFMA_PEAK_TFLOPS,
-            "mfma_executed_fraction": xf,
+                                   + ("RCCL over xGMI" if is_rccl else "host-callback (gloo) TEST transport - not a measurement of RCCL")
+                                   + "; step = one outer iteration (filter+QR+RR+residuals+locking), solves back to back",
+                       "N": N, "nev": nev, "nex": nex, "grid": f"{nprow}x{npcol}", "step": "outer iteration",
+                       "transport": "rccl" if is_rccl else "host"},
+            "eigenpairs_per_sec": nev / solve_s, "solve_seconds": solve_s, "complete_solves": len(complete),
+            "pct_fp64_mfma_peak": 100.0 * exec_flops / filt_s / 1e12 / world / B.FP64_MFMA_PEAK_TFLOPS,
             "converged": ok, "max_resid": float(np.max(resid)), "spectrum_check": spec,
-            "iterations": last["iterations"], "filtered_vecs_per_solve": (vecs + reused) / args.steps,
-            "hemm_vecs_per_solve": vecs / args.steps, "first_step_vecs_from_rr_per_solve": reused / args.steps,
-            "phase_seconds_last_solve": {k: last[k] for k in ("t_all", "t_init", "t_lanczos", "t_filter", "t_qr", "t_rr", "t_resid")},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<cplx,op,TAG=1> (filter HEMM, per GPU)",
-                         "achieved": gflops / 1e3 / world, "peak": B.FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": gflops / 1e3 / world / B.FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "executed": xf * gflops / 1e3 / world,
-                         "executed_frac": xf * gflops / 1e3 / world / B.FP64_MFMA_PEAK_TFLOPS,
-                         "launches": calls,
-                         "note": "per GPU; filter time includes the row/column all-reduces; achieved = algorithmic flops "
-                                 "(reference model, F = 4 complex) / time, executed = the 3/4 of it the matrix cores run "
-                                 "when the 3M complex scheme applies"},
+            "iterations_per_solve": st["iterations"], "filtered_vecs_per_solve": st["filtered_vecs"],
+            "timed": {"filtered_vecs": timer.filtered_timed, "hemm_vecs": hemm_vecs, "first_step_vecs_from_rr": reused,
+                      "filter_seconds_device": filt_s, "wall_seconds": wall,
+                      "iterations": [{"solve": a, "iteration": b, "filtered_vecs": c, "seconds": d}
+                                     for a, b, c, d in timer.per_iter]},
+            "phase_seconds_last_complete_solve": {k: st[k] for k in B.PHASES},
+            # diagnosis of the multi-GPU run: what RCCL itself reports, and how long the compute stream sat waiting for a
+            # collective with nothing else to run (bracketing events around every wait on the communication stream)
+            "ranks_seen_by_rccl": {"row_communicator": rccl_row, "col_communicator": rccl_col,
+                                   "grid": rccl_row * rccl_col if is_rccl else None},
+            "comm_exposed_ms": exposed_ms, "comm_exposed_frac_of_wall": exposed_ms * 1e-3 / wall,
+            "comm_waits": int(timer.diff("waits")),
+            "roofline": B.roofline_object(model_flops, exec_flops, filt_s, calls, world,
+                                          "; filter time includes the row/column all-reduces"),
         }
     s.close()
     grid.close()
+    del dH
     ctx.close()
     ctypes.CDLL(None).fflush(None)
     dist.barrier()

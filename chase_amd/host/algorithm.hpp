@@ -35,10 +35,15 @@ struct SolveStats {
     std::vector<std::size_t> iter_unconverged, iter_filtered, iter_maxdeg;
 };
 
-// optional observer of the virtual-call sequence (tests compare it against the oracle's trace)
+// optional observer of the virtual-call sequence (tests compare it against the oracle's trace) and of the outer
+// iterations (bench.py times single iterations through `iter_hook`: called after Lock() of every outer iteration with
+// the iteration index, the filtered-vector count of that iteration and the locked / unconverged counts after it; a
+// non-zero return ends the iteration loop early - the solve then finishes like one that ran into maxIter)
 struct CallTrace {
     std::vector<std::string> lines;
     bool enabled = false;
+    int (*iter_hook)(void* user, std::size_t iteration, std::size_t filtered, std::size_t locked, std::size_t unconverged) = nullptr;
+    void* iter_user = nullptr;
     void add(const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 };
 inline void CallTrace::add(const char* fmt, ...)
@@ -461,7 +466,8 @@ public:
             t0 = clock::now();
             if (tr) tr->add("filter it=%zu unconverged=%zu deg=%zu", iteration, unconverged, deg);
             k->FilterPhaseStart();
-            st->filtered_vecs += filter_H2(k, unconverged, degrees, lambda_1, lower, b_sup);
+            const std::size_t Av_it = filter_H2(k, unconverged, degrees, lambda_1, lower, b_sup);
+            st->filtered_vecs += Av_it;
             k->FilterPhaseEnd();
             st->t_filter += since(t0);
             k->ApplyKconjugate(unconverged);
@@ -496,6 +502,8 @@ public:
             locked += new_conv;
             unconverged -= new_conv;
             ++iteration;
+            st->iterations = iteration; st->locked = locked;
+            if (tr && tr->iter_hook && tr->iter_hook(tr->iter_user, iteration - 1, Av_it, locked, unconverged)) break;
         }
         // positive Ritz values first (ascending), then the rest
         std::size_t n_re = locked + unconverged;
@@ -639,6 +647,8 @@ public:
             locked += new_converged;
             unconverged -= new_converged;
             ++iteration;
+            st->iterations = iteration; st->locked = locked;
+            if (tr && tr->iter_hook && tr->iter_hook(tr->iter_user, iteration - 1, Av, locked, unconverged)) break;
         }
 
         // final ordering of the nev wanted pairs by eigenvalue: follow the cycles of the sorting permutation

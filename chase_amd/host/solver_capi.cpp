@@ -233,6 +233,14 @@ int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* out)
     return rc;
 }
 
+int chase_hip_solver_set_iteration_hook(chase_hip_solver* s, chase_hip_iteration_fn fn, void* user)
+{
+    if (!s) return chase_hip::set_error(CHASE_HIP_EINVAL, "set_iteration_hook: NULL solver");
+    s->trace.iter_hook = fn;
+    s->trace.iter_user = user;
+    return 0;
+}
+
 int chase_hip_solver_solve(chase_hip_solver* s, int record_trace)
 {
     if (!s) return chase_hip::set_error(CHASE_HIP_EINVAL, "solver_solve: NULL solver");

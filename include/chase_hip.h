@@ -66,10 +66,18 @@ int chase_hip_gemm_d(chase_hip_ctx* ctx, char opA, int m, int n, int k, double a
 int chase_hip_gemm_z(chase_hip_ctx* ctx, char opA, int m, int n, int k, const double alpha[2], const void* A,
                      long lda, const void* B, long ldb, const double beta[2], void* C, long ldc);
 
-/* 1 when complex products issued in phases 1 and 2 (chase_hip_ctx_set_phase) use the three-multiplication scheme
- * (default; CHASE_HIP_GEMM3M=0 selects the four-multiplication kernel).  It applies to launches with m a multiple of 128,
- * k a multiple of 8 and 16-byte addressable operands; other shapes take the four-multiplication kernel. */
+/* 1 when complex products issued in phase 1 (chase_hip_ctx_set_phase: the Chebyshev filter) use the three-multiplication
+ * scheme (default; CHASE_HIP_GEMM3M=0 or chase_hip_set_gemm3m(0) selects the four-multiplication kernel, the arithmetic
+ * of the reference's zgemm).  It applies to launches with m a multiple of 128, k a multiple of 8 and 16-byte addressable
+ * operands; other shapes, and every product outside the filter (Rayleigh-Ritz, residuals, Gram matrices), take the
+ * four-multiplication kernel. */
 int chase_hip_gemm3m_enabled(void);
+int chase_hip_set_gemm3m(int on); /* process-wide run-time switch */
+/* GEMM books of a context, per phase (0 other, 1 filter, 2 H-times-block outside the filter): flops in the reference's
+ * model (2*F*m*n*k, F = 4 complex: algorithm/performance.hpp:152,250), flops the matrix cores actually executed (3/4 of
+ * the model for three-multiplication launches) and the number of products.  Any output pointer may be NULL. */
+int chase_hip_ctx_gemm_counters(chase_hip_ctx* ctx, int phase, double* flops_model, double* flops_executed,
+                                unsigned long long* calls, int reset);
 /* register-resident v_mfma_f64_16x16x4_f64 issue-rate probe: returns achieved TFLOP/s */
 int chase_hip_mfma_f64_peak(chase_hip_ctx* ctx, double* tflops);
 /* streaming-copy probe: achieved HBM GB/s for a bytes-sized device-to-device float4 copy */
@@ -77,8 +85,9 @@ int chase_hip_hbm_copy_peak(chase_hip_ctx* ctx, size_t bytes, double* gbps);
 
 /* phase 1 = inside FilterPhaseStart/End: GEMMs are launched through the filter-tagged kernel symbol so that rocprofv3
  * reports the Chebyshev-filter HEMM separately; phase 2 = an H-times-block product outside the filter (Rayleigh-Ritz,
- * residuals): ordinary symbol.  Complex products of phases 1 and 2 may use the three-multiplication scheme (see
- * chase_hip_gemm3m_enabled); 0 = everything else (always four multiplications) */
+ * residuals): ordinary symbol, four multiplications (CHASE_HIP_GEMM3M_RR=1 opts them into the three-multiplication
+ * scheme).  Complex products of phase 1 may use the three-multiplication scheme (see chase_hip_gemm3m_enabled);
+ * 0 = everything else (always four multiplications) */
 int chase_hip_ctx_set_phase(chase_hip_ctx* ctx, int phase);
 
 /* ---- on-device input generators (global-index addressed, shard-safe) ------------------------------------------ */

@@ -26,6 +26,9 @@ extern "C" {
 typedef struct chase_hip_grid chase_hip_grid;
 typedef int (*chase_hip_host_allreduce_fn)(void* user, int group, double* buf, size_t count);
 typedef int (*chase_hip_host_bcast_fn)(void* user, int group, double* buf, size_t count, int root);
+/* send `sendcount` doubles to group member peer_send (< 0: nothing to send) and receive recvcount from peer_recv */
+typedef int (*chase_hip_host_sendrecv_fn)(void* user, int group, const double* sendbuf, size_t sendcount, int peer_send,
+                                          double* recvbuf, size_t recvcount, int peer_recv);
 
 int chase_hip_rccl_unique_id(char id[CHASE_HIP_UNIQUE_ID_BYTES]);
 /* id_row / id_col: the unique ids of THIS rank's row group and column group (ignored when that group has size 1) */
@@ -50,6 +53,21 @@ int chase_hip_grid_event_record(chase_hip_grid* g, int slot);
 int chase_hip_grid_event_wait(chase_hip_grid* g, int slot);
 /* all ranks agree on the maximum of a host integer (control-flow decisions such as the potrf info) */
 int chase_hip_grid_agree_max(chase_hip_grid* g, int* value);
+/* point-to-point exchange of device doubles inside `group` — replaces ncclSendrecvWrapper / MPI_Sendrecv
+ * (grid/nccl_utils.hpp:271, linalg/distMatrix/distMultiVector.hpp:1944-1958): send to group member peer_send, receive
+ * from peer_recv (negative peer or zero count: that half is skipped; both peers == own group rank: local copy).  RCCL:
+ * ncclSend + ncclRecv in one group call on the communication stream. */
+int chase_hip_grid_sendrecv(chase_hip_grid* g, int group, const void* sendbuf, size_t sendcount, int peer_send,
+                            void* recvbuf, size_t recvcount, int peer_recv);
+int chase_hip_grid_set_host_sendrecv(chase_hip_grid* g, chase_hip_host_sendrecv_fn fn); /* host transport only */
+/* exposed communication: with profiling on, every wait of the context (compute) stream on the communication stream is
+ * bracketed by timing events; comm_exposed_ms returns the accumulated time the compute stream spent waiting with nothing
+ * else to run (synchronises the context stream), and the number of waits */
+int chase_hip_grid_set_profiling(chase_hip_grid* g, int on);
+int chase_hip_grid_comm_exposed_ms(chase_hip_grid* g, double* ms, unsigned long long* waits, int reset);
+/* which transport the grid runs on and how many ranks RCCL itself reports for this rank's row / column communicator
+ * (ncclCommCount; 1 for a group without communicator) */
+int chase_hip_grid_transport(chase_hip_grid* g, int* is_rccl, int* row_ranks, int* col_ranks);
 
 /* ---- layout helpers (pure host arithmetic, no GPU needed) ------------------------------------------------------ */
 long chase_hip_block_len(long n, int nprocs);                      /* distMatrix.hpp:2000-2007 */

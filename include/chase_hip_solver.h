@@ -55,6 +55,13 @@ int chase_hip_solver_destroy(chase_hip_solver* s);
 int chase_hip_solver_set(chase_hip_solver* s, const char* key, double value);
 int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* value);
 int chase_hip_solver_solve(chase_hip_solver* s, int record_trace);
+/* Observer of the outer iterations of chase_hip_solver_solve (the while loop of algorithm/algorithm.inc:1491-1720): called
+ * after Lock() of every iteration with the 0-based iteration index, the vectors filtered in it, and the locked / still
+ * unconverged counts after it.  A non-zero return leaves the loop (the solve ends like one that hit maxIter).  bench.py
+ * times single iterations with it; fn == NULL removes the hook. */
+typedef int (*chase_hip_iteration_fn)(void* user, size_t iteration, size_t filtered_vecs, size_t locked,
+                                      size_t unconverged);
+int chase_hip_solver_set_iteration_hook(chase_hip_solver* s, chase_hip_iteration_fn fn, void* user);
 /* Algorithm<T>::lanczos_for_H2 (algorithm/algorithm.inc:1217-1373; tests/algorithm/lanczos_for_H2_test.cpp) on a
  * pseudo-Hermitian solver: DoS-based estimates of the H^2 spectrum go to the solver's ritzv[0 .. nev+nex), *upperb = b_sup,
  * *idx = number of Ritz directions moved into the start block */

@@ -1,0 +1,332 @@
+// cpu_mock_kernel.hpp — TEST INFRASTRUCTURE, not part of the product.
+//
+// A deliberately naive CPU kernel (triple loops, cyclic Jacobi eigensolver, modified Gram-Schmidt) behind the
+// ChaseBase<double> operator surface, templated on the interface class it derives from, plus the test matrix of the
+// reference's solve tests.  Two programs share it:
+//   tests/host_driver_harness.cpp      the product's driver (chase_amd/host/algorithm.hpp) on chase_amd::ChaseBase
+//   tests/golden/ref_driver_trace.cpp  the REFERENCE's driver (chase::Solve, algorithm/algorithm.inc:1376-1788) on the
+//                                      reference's chase::ChaseBase — build container only; its output is committed as
+//                                      tests/golden/driver_trace_*.txt
+// Because both programs run bit-identical kernel arithmetic, any difference between their call traces is a difference
+// between the two drivers.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <string>
+#include <vector>
+
+using std::size_t;
+
+static void jacobi_eig(int n, std::vector<double> A, std::vector<double>& w, std::vector<double>& Z)
+{   // cyclic Jacobi for a small symmetric matrix (column-major); eigenvalues ascending, eigenvectors in Z's columns
+    Z.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) Z[i + (size_t)i * n] = 1.0;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) off += A[p + (size_t)q * n] * A[p + (size_t)q * n];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p + (size_t)q * n];
+                if (std::abs(apq) < 1e-300) continue;
+                const double theta = (A[q + (size_t)q * n] - A[p + (size_t)p * n]) / (2 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::abs(theta) + std::sqrt(theta * theta + 1));
+                const double c = 1 / std::sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = A[k + (size_t)p * n], akq = A[k + (size_t)q * n];
+                    A[k + (size_t)p * n] = c * akp - s * akq; A[k + (size_t)q * n] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = A[p + (size_t)k * n], aqk = A[q + (size_t)k * n];
+                    A[p + (size_t)k * n] = c * apk - s * aqk; A[q + (size_t)k * n] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double zkp = Z[k + (size_t)p * n], zkq = Z[k + (size_t)q * n];
+                    Z[k + (size_t)p * n] = c * zkp - s * zkq; Z[k + (size_t)q * n] = s * zkp + c * zkq;
+                }
+            }
+    }
+    std::vector<int> idx(n);
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int a, int b) { return A[a + (size_t)a * n] < A[b + (size_t)b * n]; });
+    w.resize(n);
+    std::vector<double> Zs((size_t)n * n);
+    for (int j = 0; j < n; ++j) {
+        w[j] = A[idx[j] + (size_t)idx[j] * n];
+        for (int k = 0; k < n; ++k) Zs[k + (size_t)j * n] = Z[k + (size_t)idx[j] * n];
+    }
+    Z.swap(Zs);
+}
+
+// Naive CPU kernel behind the ChaseBase<double> surface.  BaseT / ConfigT select WHICH interface it implements:
+// chase_amd::ChaseBase (the product's own driver, tests/host_driver_harness.cpp) or the reference's chase::ChaseBase
+// (tests/golden/ref_driver_trace.cpp, compiled in the build container only).  Every virtual call is appended to `calls`
+// with its scalar arguments: that list is the golden call trace.
+template <class BaseT, class ConfigT>
+class CpuMock : public BaseT {
+public:
+    CpuMock(size_t N, size_t nev, size_t nex, std::vector<double> H)
+        : N_(N), nev_(nev), nex_(nex), n_(nev + nex), H_(std::move(H)), V1_(N * n_), V2_(N * n_), ritzv_(n_), resid_(n_),
+          cfg_(N, nev, nex) {}
+    std::vector<std::string> calls;
+    void log(const char* fmt, ...) __attribute__((format(printf, 2, 3)))
+    {
+        char buf[256];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        calls.emplace_back(buf);
+    }
+
+    void Shift(double c, bool isunshift = false) override
+    {
+        log("Shift %.17g %d", c, (int)isunshift);
+        for (size_t i = 0; i < N_; ++i) H_[i + i * N_] += c;
+    }
+    void FilterPhaseStart() override { log("FilterPhaseStart"); }
+    void FilterPhaseEnd() override { log("FilterPhaseEnd"); }
+    void HEMM(size_t block, double alpha, double beta, size_t off_l, size_t off_r = 0) override
+    {
+        const size_t ncols = off_r < block ? block - off_r : 0;
+        if (off_r) log("HEMM %zu %.17g %.17g %zu %zu", block, alpha, beta, off_l, off_r);
+        else log("HEMM %zu %.17g %.17g %zu", block, alpha, beta, off_l);
+        if (ncols) {
+            const size_t c0 = locked_ + off_l;
+            for (size_t j = c0; j < c0 + ncols; ++j)
+                for (size_t i = 0; i < N_; ++i) {
+                    double s = 0;
+                    for (size_t k = 0; k < N_; ++k) s += H_[k + i * N_] * V1_[k + j * N_];   // H symmetric: H[i,k] == H[k,i]
+                    V2_[i + j * N_] = alpha * s + (beta == 0 ? 0.0 : beta * V2_[i + j * N_]);
+                }
+        }
+        V1_.swap(V2_);
+    }
+    void HEMM_H2(size_t, double, double, double, size_t, size_t = 0) override {}
+    void ApplyKconjugate(size_t) override {}
+    void QR(size_t fixednev, double cond) override
+    {
+        log("QR %zu %.17g", fixednev, cond);   // modified Gram-Schmidt, twice (same Q as CholQR up to rounding: R has a positive diagonal in both)
+        for (size_t j = 0; j < locked_; ++j) std::copy(&V1_[j * N_], &V1_[(j + 1) * N_], &V2_[j * N_]);
+        for (int pass = 0; pass < 2; ++pass)
+            for (size_t j = 0; j < n_; ++j) {
+                for (size_t p = 0; p < j; ++p) {
+                    double d = 0;
+                    for (size_t i = 0; i < N_; ++i) d += V1_[i + p * N_] * V1_[i + j * N_];
+                    for (size_t i = 0; i < N_; ++i) V1_[i + j * N_] -= d * V1_[i + p * N_];
+                }
+                double nr = 0;
+                for (size_t i = 0; i < N_; ++i) nr += V1_[i + j * N_] * V1_[i + j * N_];
+                nr = std::sqrt(nr);
+                for (size_t i = 0; i < N_; ++i) V1_[i + j * N_] /= nr;
+            }
+        for (size_t j = 0; j < locked_; ++j) std::copy(&V2_[j * N_], &V2_[(j + 1) * N_], &V1_[j * N_]);
+    }
+    void RR(double* ritzv, size_t block) override
+    {
+        log("RR %zu", block);
+        const size_t L = locked_;
+        std::vector<double> W(N_ * block), A(block * block), w, Z;
+        for (size_t j = 0; j < block; ++j)
+            for (size_t i = 0; i < N_; ++i) {
+                double s = 0;
+                for (size_t k = 0; k < N_; ++k) s += H_[k + i * N_] * V1_[k + (L + j) * N_];
+                W[i + j * N_] = s;
+            }
+        for (size_t a = 0; a < block; ++a)
+            for (size_t b = 0; b < block; ++b) {
+                double s = 0;
+                for (size_t i = 0; i < N_; ++i) s += V1_[i + (L + a) * N_] * W[i + b * N_];
+                A[a + b * block] = s;
+            }
+        for (size_t a = 0; a < block; ++a) for (size_t b = 0; b < a; ++b) A[b + a * block] = A[a + b * block];
+        jacobi_eig((int)block, A, w, Z);
+        for (size_t j = 0; j < block; ++j) {
+            ritzv[j] = w[j];
+            for (size_t i = 0; i < N_; ++i) {
+                double s = 0;
+                for (size_t k = 0; k < block; ++k) s += V1_[i + (L + k) * N_] * Z[k + j * block];
+                V2_[i + (L + j) * N_] = s;
+            }
+        }
+        V1_.swap(V2_);
+    }
+    void Sort(double*, double*, double*) override {}
+    void Resd(double* ritzv, double* resd, size_t fixednev) override
+    {
+        log("Resd %zu", fixednev);
+        const size_t L = locked_;
+        for (size_t j = L; j < n_; ++j) {
+            double r = 0;
+            for (size_t i = 0; i < N_; ++i) {
+                double s = 0;
+                for (size_t k = 0; k < N_; ++k) s += H_[k + i * N_] * V1_[k + j * N_];
+                s -= ritzv[j - L] * V1_[i + j * N_];
+                r += s * s;
+            }
+            resd[j - L] = std::sqrt(r);
+            resid_[j] = resd[j - L];
+        }
+    }
+    void Lanczos(size_t m, double* upperb) override
+    {
+        log("Lanczos1 %zu", m);
+        std::vector<double> th(m), tau(m), z(m * m), Vsave = V1_;
+        lanczos(m, 1, upperb, th.data(), tau.data(), z.data());
+        V1_ = Vsave;
+    }
+    void Lanczos(size_t M, size_t numvec, double* upperb, double* ritzv, double* Tau, double* ritzV) override
+    {
+        log("Lanczos %zu %zu", M, numvec);
+        lanczos(M, numvec, upperb, ritzv, Tau, ritzV);
+    }
+    void LanczosDos(size_t idx, size_t m, double* ritzVc) override
+    {
+        log("LanczosDos %zu %zu", idx, m);
+        for (size_t j = 0; j < idx; ++j)
+            for (size_t i = 0; i < N_; ++i) {
+                double s = 0;
+                for (size_t k = 0; k < m; ++k) s += V1_[i + k * N_] * ritzVc[k + j * m];
+                V2_[i + j * N_] = s;
+            }
+        for (size_t j = 0; j < m; ++j) std::copy(&V2_[j * N_], &V2_[(j + 1) * N_], &V1_[j * N_]);
+    }
+    void Swap(size_t i, size_t j) override
+    {
+        log("Swap %zu %zu", i, j);
+        for (size_t k = 0; k < N_; ++k) std::swap(V1_[k + i * N_], V1_[k + j * N_]);
+    }
+    void Lock(size_t k) override { log("Lock %zu", k); locked_ += k; }
+    bool checkSymmetryEasy() override { return true; }
+    bool isSym() override { return true; }
+    bool checkPseudoHermicityEasy() override { return false; }
+    bool isPseudoHerm() override { return false; }
+    void symOrHermMatrix(char) override {}
+    void Start() override { log("Start"); locked_ = 0; }
+    void End() override { log("End"); }
+    void initVecs(bool random) override
+    {
+        log("initVecs %d", (int)random);
+        if (random) {                                   // chase_cpu.hpp:296-309: mt19937(1337), column-major fill
+            std::mt19937 gen(1337.0);
+            std::normal_distribution<> d;
+            for (auto& x : V1_) x = d(gen);
+        }
+        V2_ = V1_;
+    }
+    size_t GetN() const override { return N_; }
+    size_t GetNev() override { return nev_; }
+    size_t GetNex() override { return nex_; }
+    size_t GetLanczosIter() override { return lanczosIter_; }
+    size_t GetNumLanczos() override { return numLanczos_; }
+    size_t GetRitzvBlockSize() const override { return n_; }
+    double* GetRitzv() override { return ritzv_.data(); }
+    double* GetResid() override { return resid_.data(); }
+    ConfigT& GetConfig() override { return cfg_; }
+    int get_nprocs() override { return 1; }
+    int get_rank() override { return 0; }
+
+private:
+    void lanczos(size_t M, size_t nv, double* upperb, double* theta, double* Tau, double* ritzV)
+    {   // cpu/lanczos.hpp:46-209
+        lanczosIter_ = M; numLanczos_ = nv;
+        std::vector<double> v0(N_ * nv, 0.0), v1(N_ * nv), v2(N_ * nv), d(M * nv, 0.0), e(M * nv, 0.0), rb(nv, 0.0);
+        for (size_t j = 0; j < nv; ++j) {
+            double nr = 0;
+            for (size_t i = 0; i < N_; ++i) nr += V1_[i + j * N_] * V1_[i + j * N_];
+            nr = std::sqrt(nr);
+            for (size_t i = 0; i < N_; ++i) v1[i + j * N_] = V1_[i + j * N_] / nr;
+        }
+        for (size_t k = 0; k < M; ++k) {
+            for (size_t i = 0; i < N_; ++i) V1_[i + k * N_] = v1[i + (nv - 1) * N_];
+            for (size_t j = 0; j < nv; ++j) {
+                for (size_t i = 0; i < N_; ++i) {
+                    double s = 0;
+                    for (size_t q = 0; q < N_; ++q) s += H_[q + i * N_] * v1[q + j * N_];
+                    v2[i + j * N_] = s;
+                }
+                double a = 0;
+                for (size_t i = 0; i < N_; ++i) a += v1[i + j * N_] * v2[i + j * N_];
+                for (size_t i = 0; i < N_; ++i) v2[i + j * N_] -= a * v1[i + j * N_];
+                d[k + M * j] = a;
+                if (k > 0) for (size_t i = 0; i < N_; ++i) v2[i + j * N_] -= rb[j] * v0[i + j * N_];
+                double nr = 0;
+                for (size_t i = 0; i < N_; ++i) nr += v2[i + j * N_] * v2[i + j * N_];
+                rb[j] = std::sqrt(nr);
+            }
+            if (k == M - 1) break;
+            for (size_t j = 0; j < nv; ++j) {
+                for (size_t i = 0; i < N_; ++i) v2[i + j * N_] /= rb[j];
+                e[k + M * j] = rb[j];
+            }
+            v0.swap(v1); v1.swap(v2);
+        }
+        for (size_t j = 0; j < nv; ++j) std::copy(&v1[j * N_], &v1[(j + 1) * N_], &V1_[j * N_]);
+        double ub = 0;
+        for (size_t j = 0; j < nv; ++j) {
+            std::vector<double> T(M * M, 0.0), w, Z;
+            for (size_t k = 0; k < M; ++k) {
+                T[k + k * M] = d[k + M * j];
+                if (k + 1 < M) { T[k + 1 + k * M] = e[k + M * j]; T[k + (k + 1) * M] = e[k + M * j]; }
+            }
+            jacobi_eig((int)M, T, w, Z);
+            for (size_t k = 0; k < M; ++k) {
+                theta[k + j * M] = w[k];
+                if (Tau) Tau[k + j * M] = Z[0 + k * M] * Z[0 + k * M];
+            }
+            if (ritzV) std::copy(Z.begin(), Z.end(), ritzV);
+            const double cand = std::max(std::abs(w[0]), std::abs(w[M - 1])) + std::abs(rb[j]);
+            ub = (j == 0) ? cand : std::max(ub, cand);
+        }
+        *upperb = ub;
+    }
+
+    size_t N_, nev_, nex_, n_;
+    std::vector<double> H_, V1_, V2_, ritzv_, resid_;
+    ConfigT cfg_;
+    size_t locked_ = 0, lanczosIter_ = 0, numLanczos_ = 0;
+};
+
+
+// Clement-type matrix of the reference's solve tests with its seeded symmetric perturbation
+// (tests/chase_serial_solve.cpp:52-90: mt19937(42), entries 1 <= j < i < N, real: eps * N(0,1))
+inline std::vector<double> clement_matrix(size_t N, double perturb)
+{
+    std::vector<double> H(N * N, 0.0);
+    for (size_t i = 0; i + 1 < N; ++i) {
+        const double v = std::sqrt((double)i * (double)(N + 1 - i));
+        H[i + 1 + i * N] = v; H[i + (i + 1) * N] = v;
+    }
+    if (perturb != 0.0) {
+        std::mt19937 gen(42);
+        std::normal_distribution<> d;
+        for (size_t i = 1; i < N; ++i)
+            for (size_t j = 1; j < i; ++j) {
+                const double ep = d(gen) * perturb;
+                H[j + N * i] += ep;
+                H[i + N * j] += ep;
+            }
+    }
+    return H;
+}
+
+// the run both programs print: counts derived from the kernel-side call list, eigenpairs, then the list itself
+template <class Mock>
+inline void print_run(Mock& k, size_t nev)
+{
+    size_t iterations = 0, filtered = 0;
+    bool in_filter = false;
+    for (const auto& l : k.calls) {
+        if (l == "FilterPhaseStart") in_filter = true;
+        else if (l == "FilterPhaseEnd") in_filter = false;
+        else if (l.rfind("RR ", 0) == 0) ++iterations;
+        else if (in_filter && l.rfind("HEMM ", 0) == 0) filtered += std::strtoul(l.c_str() + 5, nullptr, 10);
+    }
+    std::printf("iterations %zu\nfiltered_vecs %zu\n", iterations, filtered);
+    for (size_t i = 0; i < nev; ++i) std::printf("lambda %.15e %.6e\n", k.GetRitzv()[i], k.GetResid()[i]);
+    for (const auto& l : k.calls) std::printf("call %s\n", l.c_str());
+}

@@ -1,0 +1,71 @@
+"""bench.py contract on a box without a GPU: the iteration-step timer, and the self-launching multi-rank entry point."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench as B  # noqa: E402
+
+
+class FakeSolver:
+    """Stands in for the C++ driver: a 'solve' of `iters` outer iterations that calls the iteration observer."""
+
+    def __init__(self, iters=9, nev=10):
+        self.iters, self.nev, self.hook, self.calls, self.aborted = iters, nev, None, 0, 0
+        self.counters = {"it": 0}
+
+    def set_iteration_hook(self, fn):
+        self.hook = fn
+
+    def solve(self):
+        self.calls += 1
+        for it in range(self.iters):
+            self.counters["it"] += 1
+            if self.hook and self.hook(it, 100 - it, it, self.iters - it):
+                self.aborted += 1
+                return {"locked": 0, "t_all": 0.0}
+        return {"locked": self.nev, "t_all": 1.0}
+
+
+@pytest.mark.parametrize("steps,warmup", [(6, 3), (20, 5), (1, 0), (9, 0), (2, 17)])
+def test_step_timer_times_exactly_k_iterations(steps, warmup):
+    s = FakeSolver()
+    events = []
+    timer = B.StepTimer(steps, warmup, lambda: events.append("sync"), lambda: events.append("barrier"),
+                        lambda: dict(s.counters))
+    complete, last = B.run_timed_solves(s, timer, s.nev, lambda: ("lam", "res"))
+    assert timer.done and timer.diff("it") == steps                       # exactly K iterations between the brackets
+    assert timer.c0["it"] == warmup                                        # after exactly W untimed ones
+    assert len(timer.per_iter) == steps
+    assert events == ["sync", "barrier", "sync", "barrier"]                # one bracket on each side, sync before barrier
+    assert len(complete) >= 1 and last == ("lam", "res")                   # a complete solve backs the parity guard
+    # solves run back to back; the solve in flight when the timed region ends is cut short only if a complete one exists
+    total = warmup + steps
+    assert s.calls == max(1, -(-total // s.iters))
+    assert timer.filtered_timed == sum(100 - (i % s.iters) for i in range(warmup, total))
+
+
+def test_roofline_fraction_is_executed_and_bounded():
+    r = B.roofline_object(model_flops=4.0e15, exec_flops=3.0e15, filt_s=50.0, calls=100, world=1)
+    assert r["frac"] == pytest.approx(60.0 / B.FP64_MFMA_PEAK_TFLOPS) and r["frac"] <= 1.0
+    assert r["algorithmic"] == pytest.approx(80.0) and r["achieved"] == pytest.approx(60.0)
+    assert r["executed_over_model"] == pytest.approx(0.75)
+
+
+def test_multi_rank_launch_starts_its_own_ranks_and_fails_only_for_lack_of_a_device():
+    """`python bench.py --gpus 2` must get through the rendezvous by itself (no launcher, no RANK in the environment); on
+    a box without a GPU the ranks then stop at the device check and the parent exits non-zero without a result line."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0
+    assert "no usable device context" in p.stderr and "no HIP device visible" in p.stderr
+    assert "RANK expected" not in p.stderr and "environment variable" not in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -96,8 +96,33 @@ def test_clement_n256_solve_matches_oracle(ctx, cplx):
     assert O.orthogonality(V) < 1e-9
     assert abs(st["iterations"] - so["iterations"]) <= 1
     assert abs(st["filtered_vecs"] - so["filtered_vecs"]) <= 0.05 * so["filtered_vecs"]
-    tr_g = s.trace()
-    assert tr_g[:3] == tr_o[:3]                                            # initVecs, QR 0 1, Lanczos m numvec
+    # the WHOLE driver-level call sequence (every HEMM with its alpha / beta / offset, QR cond, RR, Resd, Lock counts)
+    import golden_traces as G
+    G.assert_same_calls(s.trace(), tr_o, 1e-6, "HIP path vs oracle")
+    assert st["iterations"] == so["iterations"] and st["filtered_vecs"] == so["filtered_vecs"]
+    s.close()
+
+
+@pytest.mark.parametrize("name", ["clement256", "clement256_fix", "clement512", "clement1001", "clement1200"])
+def test_hip_path_issues_the_reference_drivers_calls(ctx, name):
+    """tests/golden/driver_trace_*.txt: runs of the REFERENCE's own chase::Solve (compiled from the reference sources in the
+    build container, tests/golden/make_driver_traces.sh) on a naive CPU kernel.  The HIP Impl under the product's driver must
+    issue the same driver-level calls from the first to the last: same iteration and filtered-vector counts, every HEMM
+    with the same width / alpha / beta / offset, the same QR condition estimates, RR / Resd / Lock arguments."""
+    import golden_traces as G
+    from chase_amd.capi import Solver
+    N, nev, nex, deg, opt, perturb = G.CASES[name]
+    want = G.load(name)
+    H = O.clement(N, False, perturb=perturb)
+    s = Solver(ctx, H, nev, nex)
+    s.set(deg=deg, opt=opt)
+    st = s.solve(trace=True)
+    assert st["iterations"] == want["iterations"]
+    assert st["filtered_vecs"] == want["filtered_vecs"]
+    G.assert_same_calls([t for t in s.trace() if t.split()[0] not in ("bounds", "filter")], G.core(want["calls"]), 1e-6,
+                        "HIP path")
+    assert np.max(np.abs(s.ritzv[:nev] - np.array(want["lam"]))) < 1e-9
+    assert np.max(s.resid()[:nev]) <= 1e-10
     s.close()
 
 
