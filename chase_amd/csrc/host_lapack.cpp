@@ -1,6 +1,9 @@
 // host_lapack.cpp — dlopen-bound LAPACK (LP64, Fortran calling convention).
 // Providers tried in order: $CHASE_HIP_LAPACK_LIB, an explicit hint, scipy's bundled OpenBLAS (LP64, "scipy_" prefix),
-// MKL's single dynamic library.  No provider => CHASE_HIP_ELAPACK (the product never falls back silently).
+// MKL's single dynamic library.  No provider (or CHASE_HIP_LAPACK_LIB=builtin) => the library's own implementations
+// (host_eig_builtin.cpp: Householder + implicit QL, Cholesky, triangular solves), reported as provider "builtin", so that a
+// plain C application on a box without MKL / OpenBLAS still works (the reference links a LAPACK at build time,
+// external/lapackpp/lapackpp.hpp).
 #include <dlfcn.h>
 #include <glob.h>
 #include <cmath>
@@ -40,6 +43,12 @@ static trsm_t g_dtrsm = nullptr, g_ztrsm = nullptr;
 static set_threads_t g_set_threads = nullptr;
 static std::string g_provider;
 static std::mutex g_mu;
+static bool g_builtin = false;
+
+int builtin_tridiag_eig(int n, double* d, double* e, double* w, double* Z, int ldz);
+int builtin_heevd(bool cplx, int n, double* A, int lda, double* w);
+int builtin_potrf_lower(bool cplx, int n, double* A, int lda);
+void builtin_trsm_lower(bool cplx, char side, char op, int n, const double* L, int ldl, double* B, int ldb);
 
 static void* sym_any(void* h, const char* base)
 {
@@ -95,8 +104,14 @@ static bool try_glob(const char* pattern)
 int lapack_bind(const char* hint)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_handle) return 0;
-    if (try_lib(getenv("CHASE_HIP_LAPACK_LIB"))) return 0;
+    if (g_handle || g_builtin) return 0;
+    const char* forced = getenv("CHASE_HIP_LAPACK_LIB");
+    if ((forced && strcmp(forced, "builtin") == 0) || (hint && strcmp(hint, "builtin") == 0)) {
+        g_builtin = true;
+        g_provider = "builtin";
+        return 0;
+    }
+    if (try_lib(forced)) return 0;
     if (try_lib(hint)) return 0;
     // 1) MKL's single dynamic library: a PRIVATE provider (numpy/scipy in the same process use their own OpenBLAS), so
     //    its thread count can be tuned without side effects.  LP64 interface, GNU threading layer (libgomp).
@@ -113,8 +128,10 @@ int lapack_bind(const char* hint)
     };
     for (const char* p : pats)
         if (try_glob(p)) return 0;
-    return set_error(CHASE_HIP_ELAPACK,
-                     "no host LAPACK provider found (set CHASE_HIP_LAPACK_LIB to an LP64 LAPACK shared library)");
+    // 3) nothing to bind: the library's own small eigensolvers (slower, same contracts)
+    g_builtin = true;
+    g_provider = "builtin";
+    return 0;
 }
 
 const char* lapack_provider() { return g_provider.c_str(); }
@@ -129,6 +146,10 @@ int host_heevd(bool cplx, int n, double* A, int lda, double* w)
     if (n <= 0) return 0;
     int rc = lapack_bind(nullptr);
     if (rc) return rc;
+    if (g_builtin) {
+        const int bi = builtin_heevd(cplx, n, A, lda, w);
+        return bi ? set_error(CHASE_HIP_ENOTCONV, "builtin heevd: QL iteration did not converge") : 0;
+    }
     int info = 0, lwork = -1, lrwork = -1, liwork = -1;
     const char jobz = 'V', uplo = 'L';
     if (!cplx) {
@@ -167,19 +188,27 @@ int host_pseudo_rr(bool cplx, int n, double* A, double* M, double* w)
     if (rc) return rc;
     potrf_t potrf = cplx ? g_zpotrf : g_dpotrf;
     trsm_t trsm = cplx ? g_ztrsm : g_dtrsm;
-    if (!potrf || !trsm) return set_error(CHASE_HIP_ELAPACK, "host LAPACK provider lacks potrf/trsm");
+    const bool own = g_builtin || !potrf || !trsm;          // a provider without potrf / trsm: the own ones serve
     const int E = cplx ? 2 : 1;
     int info = 0;
+    const double one[2] = {1.0, 0.0};
+    if (own) {
+        info = builtin_potrf_lower(cplx, n, A, n);
+        if (info != 0) return info;
+        builtin_trsm_lower(cplx, 'L', 'N', n, A, n, M, n);
+        builtin_trsm_lower(cplx, 'R', 'C', n, A, n, M, n);
+    } else {
     potrf("L", &n, A, &n, &info);
     if (info != 0) return info > 0 ? info : set_error(CHASE_HIP_EINVAL, "host potrf: illegal argument");
-    const double one[2] = {1.0, 0.0};
     trsm("L", "L", "N", "N", &n, &n, one, A, &n, M, &n);
     trsm("R", "L", "C", "N", &n, &n, one, A, &n, M, &n);
+    }
     for (size_t i = 0; i < (size_t)n * n * E; ++i) M[i] = -M[i];
     rc = host_heevd(cplx, n, M, n, w);
     if (rc) return rc;
     for (int i = 0; i < n; ++i) w[i] = -w[i];
-    trsm("L", "L", "C", "N", &n, &n, one, A, &n, M, &n);
+    if (own) builtin_trsm_lower(cplx, 'L', 'C', n, A, n, M, n);
+    else trsm("L", "L", "C", "N", &n, &n, one, A, &n, M, &n);
     for (int i = 0; i < n; ++i) w[i] = 1.0 / w[i];
     for (int j = 0; j < n / 2; ++j) {
         double s = 0.0;
@@ -197,7 +226,7 @@ int host_stedc(int n, double* d, double* e, double* w, double* Z, int ldz)
     if (n <= 0) return 0;
     int rc = lapack_bind(nullptr);
     if (rc) return rc;
-    if (!g_dstedc) return host_stemr(n, d, e, w, Z, ldz);
+    if (g_builtin || !g_dstedc) return host_stemr(n, d, e, w, Z, ldz);
     const char compz = 'I';
     int info = 0, lwork = -1, liwork = -1, iwq;
     double wq;
@@ -221,6 +250,10 @@ int host_stemr(int n, double* d, double* e, double* w, double* Z, int ldz)
     if (n <= 0) return 0;
     int rc = lapack_bind(nullptr);
     if (rc) return rc;
+    if (g_builtin) {
+        const int bi = builtin_tridiag_eig(n, d, e, w, Z, ldz);
+        return bi ? set_error(CHASE_HIP_ENOTCONV, "builtin tridiagonal QL iteration did not converge") : 0;
+    }
     const char jobz = 'V', range = 'A';
     const double vl = 0, vu = 0;
     const int il = 0, iu = 0;

@@ -127,4 +127,50 @@ int chase_hip_save_matrix(chase_hip_ctx* c, const char* path, int cplx, int m, i
     return 0;
 }
 
+/* the counterpart of chase_hip_load_matrix_shard: this rank's block-cyclic shard goes to its byte ranges of the shared
+ * N x N file (one pwrite per local column and row block).  The file is created if missing and never truncated, so the
+ * ranks of a grid may call this concurrently on the same path (the reference writes through an MPI-IO darray / subarray
+ * view, linalg/distMatrix/distMatrix.hpp:2241-2300,3117-3200). */
+int chase_hip_save_matrix_shard(chase_hip_ctx* c, const char* path, int cplx, long N, int mloc, int nloc, int mb, int pr,
+                                int pi, int nb, int pc, int pj, const void* dev, long ldd)
+{
+    if (!c || !path || (!dev && mloc > 0 && nloc > 0)) return set_error(CHASE_HIP_EINVAL, "save_matrix_shard: NULL argument");
+    (void)hipSetDevice(c->device);
+    if (N <= 0 || mloc < 0 || nloc < 0 || mb <= 0 || nb <= 0 || pr <= 0 || pc <= 0 || pi < 0 || pi >= pr || pj < 0 ||
+        pj >= pc || ldd < mloc)
+        return set_error(CHASE_HIP_EINVAL, "save_matrix_shard: bad shape");
+    const size_t es = cplx ? 16 : 8;
+    Fd f;
+    f.fd = ::open(path, O_WRONLY | O_CREAT, 0644);
+    if (f.fd < 0) return io_error("save_matrix_shard: cannot open", path);
+    if (mloc == 0 || nloc == 0) return 0;
+    const long g_last_r = ((long)((mloc - 1) / mb) * pr + pi) * mb + (mloc - 1) % mb;
+    const long g_last_c = ((long)((nloc - 1) / nb) * pc + pj) * nb + (nloc - 1) % nb;
+    if (g_last_r >= N || g_last_c >= N) return set_error(CHASE_HIP_EINVAL, "save_matrix_shard: shard exceeds the matrix");
+    const size_t col_bytes = (size_t)mloc * es;
+    int pcols = (int)std::max<size_t>(1, std::min<size_t>((size_t)nloc, ((size_t)256 << 20) / col_bytes));
+    int rc = c->ensure_hstage((size_t)pcols * col_bytes);
+    if (rc) return rc;
+    const char* stage = (const char*)c->hstage;
+    for (int j0 = 0; j0 < nloc; j0 += pcols) {
+        const int w = std::min(pcols, nloc - j0);
+        hipError_t e = hipMemcpy2DAsync(c->hstage, col_bytes, (const char*)dev + (size_t)j0 * ldd * es, (size_t)ldd * es,
+                                        col_bytes, (size_t)w, hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) return hip_fail(e, "save_matrix_shard: download");
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return set_error(CHASE_HIP_EIO, "save_matrix_shard: sync failed");
+        for (int j = 0; j < w; ++j) {
+            const int lj = j0 + j;
+            const long gj = ((long)(lj / nb) * pc + pj) * nb + lj % nb;
+            for (int i0 = 0; i0 < mloc; i0 += mb) {
+                const int h = std::min(mb, mloc - i0);
+                const long gi = ((long)(i0 / mb) * pr + pi) * mb;
+                const off_t off = (off_t)(((unsigned long long)gj * (unsigned long long)N + (unsigned long long)gi) * es);
+                if (!full_pwrite(f.fd, stage + ((size_t)j * mloc + i0) * es, (size_t)h * es, off))
+                    return io_error("save_matrix_shard: short write to", path);
+            }
+        }
+    }
+    return 0;
+}
+
 } // extern "C"

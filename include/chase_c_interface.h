@@ -12,9 +12,18 @@
  *   ?chase_get_eigenpairs_(LEigsV, ld, ritzv): first nev eigenvectors (N x nev, ld >= N) and Ritz values (:177-181)
  *   zchase_init_pseudo_[internal_] / zchase_pseudo_ : pseudo-Hermitian (Bethe-Salpeter) problems through chase::Solve_pseudo;
  *              V has 2*(nev+nex) columns, ritzv 2*(nev+nex) entries (:44-58); zchase_ solves whichever type was initialised
- * The GPU is chosen by CHASE_HIP_DEVICE (default 0).  Single precision and the distributed p?chase_* entry points (they
- * take an MPI_Comm; this image has no MPI) are not provided by this fp64, single-process shim — the distributed Impl is
- * reached through chase_hip_solver.h. */
+ * The GPU is chosen by CHASE_HIP_DEVICE (default 0).  Single precision is not provided (this backend is fp64).
+ *
+ * Distributed entry points (interface/chase_c_interface.h:61-65,95-99,126-128,149,177-195): every p?chase_init* of the
+ * reference takes an MPI_Comm* and builds the 2D grid from it.  libchase_hip.so exports the same entry points with the
+ * communicator replaced by a chase_hip_grid* (suffix _hip_; the grid carries dims, coordinates and the RCCL row / column
+ * communicators; tell the shim the grid's device context first: chase_hip_cshim_use_ctx), and libchase_hip_mpi.so (built
+ * when mpi.h is found; chase_amd/host/c_interface_mpi.c) exports the reference's exact MPI_Comm* signatures on top of
+ * them.  H is the caller's HOST block of the local rows / columns (m x n, ldh); V the host block of local rows
+ * (m x (nev+nex), ld = m; 2*(nev+nex) columns for pseudo-Hermitian problems), read when mode == 'A' and written by the
+ * solve; mbsize / nbsize select the block-cyclic layout, irsrc / icsrc must be 0.  After init the names are the
+ * reference's: p?chase_, p?chase_get_eigenpairs_ (local rows of the first nev vectors), p?chase_finalize_,
+ * p?chase_readHam_ / p?chase_wrtHam_ (the local shard from / to a raw column-major N x N file). */
 #ifndef CHASE_C_INTERFACE_HIP_H
 #define CHASE_C_INTERFACE_HIP_H
 #ifdef __cplusplus
@@ -34,6 +43,47 @@ void zchase_pseudo_(int* deg, double* tol, char* mode, char* opt, char* qr);
 void dchase_get_eigenpairs_(double* LEigsV, int* ld, double* ritzv);
 void zchase_get_eigenpairs_(void* LEigsV, int* ld, double* ritzv);
 void chase_enable_sym_check_(int* flag);     /* interface/chase_c_interface.cpp:4055: flag kept for callers that set it */
+
+/* ---- distributed (one process per GPU) ---- */
+struct chase_hip_grid;
+struct chase_hip_ctx;
+struct chase_hip_solver;
+int chase_hip_cshim_use_ctx(struct chase_hip_ctx* ctx, int own); /* context of the NEXT _hip_ init; own: finalize destroys grid + ctx */
+struct chase_hip_solver* chase_hip_cshim_dist_solver(int cplx); /* the live distributed solver (chase_hip_solver.h), or NULL */
+void pdchase_init_hip_(int* N, int* nev, int* nex, int* m, int* n, double* H, int* ldh, double* V, double* ritzv,
+                       struct chase_hip_grid* grid, int* init);
+void pdchase_init_internal_hip_(int* N, int* nev, int* nex, int* m, int* n, double* H, int* ldh,
+                                struct chase_hip_grid* grid, int* init);
+void pzchase_init_hip_(int* N, int* nev, int* nex, int* m, int* n, void* H, int* ldh, void* V, double* ritzv,
+                       struct chase_hip_grid* grid, int* init);
+void pzchase_init_internal_hip_(int* N, int* nev, int* nex, int* m, int* n, void* H, int* ldh,
+                                struct chase_hip_grid* grid, int* init);
+void pzchase_init_pseudo_hip_(int* N, int* nev, int* nex, int* m, int* n, void* H, int* ldh, void* V, double* ritzv,
+                              struct chase_hip_grid* grid, int* init);
+void pzchase_init_pseudo_internal_hip_(int* N, int* nev, int* nex, int* m, int* n, void* H, int* ldh,
+                                       struct chase_hip_grid* grid, int* init);
+void pdchase_init_blockcyclic_hip_(int* N, int* nev, int* nex, int* mbsize, int* nbsize, double* H, int* ldh, double* V,
+                                   double* ritzv, int* irsrc, int* icsrc, struct chase_hip_grid* grid, int* init);
+void pdchase_init_blockcyclic_internal_hip_(int* N, int* nev, int* nex, int* mbsize, int* nbsize, double* H, int* ldh,
+                                            int* irsrc, int* icsrc, struct chase_hip_grid* grid, int* init);
+void pzchase_init_blockcyclic_hip_(int* N, int* nev, int* nex, int* mbsize, int* nbsize, void* H, int* ldh, void* V,
+                                   double* ritzv, int* irsrc, int* icsrc, struct chase_hip_grid* grid, int* init);
+void pzchase_init_blockcyclic_internal_hip_(int* N, int* nev, int* nex, int* mbsize, int* nbsize, void* H, int* ldh,
+                                            int* irsrc, int* icsrc, struct chase_hip_grid* grid, int* init);
+void pzchase_init_pseudo_blockcyclic_hip_(int* N, int* nev, int* nex, int* mbsize, int* nbsize, void* H, int* ldh, void* V,
+                                          double* ritzv, int* irsrc, int* icsrc, struct chase_hip_grid* grid, int* init);
+void pzchase_init_pseudo_blockcyclic_internal_hip_(int* N, int* nev, int* nex, int* mbsize, int* nbsize, void* H, int* ldh,
+                                                   int* irsrc, int* icsrc, struct chase_hip_grid* grid, int* init);
+void pdchase_(int* deg, double* tol, char* mode, char* opt, char* qr);
+void pzchase_(int* deg, double* tol, char* mode, char* opt, char* qr);
+void pdchase_get_eigenpairs_(double* LEigsV, int* ld, double* ritzv);
+void pzchase_get_eigenpairs_(void* LEigsV, int* ld, double* ritzv);
+void pdchase_finalize_(int* flag);
+void pzchase_finalize_(int* flag);
+void pdchase_readHam_(const char* filename);
+void pzchase_readHam_(const char* filename);
+void pdchase_wrtHam_(const char* filename);
+void pzchase_wrtHam_(const char* filename);
 #ifdef __cplusplus
 }
 #endif

@@ -119,6 +119,10 @@ int chase_hip_gen_bse(chase_hip_ctx* ctx, int cplx, void* H, long ldh, int mloc,
 int chase_hip_load_matrix_shard(chase_hip_ctx* ctx, const char* path, int cplx, long N, int mloc, int nloc, int mb,
                                 int pr, int pi, int nb, int pc, int pj, void* dev, long ldd);
 int chase_hip_save_matrix(chase_hip_ctx* ctx, const char* path, int cplx, int m, int n, const void* dev, long ldd);
+/* writes this rank's block-cyclic shard into its byte ranges of the shared N x N file (created if missing, never
+ * truncated: all ranks of a grid may write the same path concurrently) — distMatrix.hpp:2241-2300,3117-3200 */
+int chase_hip_save_matrix_shard(chase_hip_ctx* ctx, const char* path, int cplx, long N, int mloc, int nloc, int mb,
+                                int pr, int pi, int nb, int pc, int pj, const void* dev, long ldd);
 
 /* ---- host LAPACK provider (HEEVD / STEMR stay on the host per the north star) --------------------------------- */
 int chase_hip_set_lapack_lib(const char* path);   /* optional explicit LP64 LAPACK shared library */

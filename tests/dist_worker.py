@@ -385,6 +385,106 @@ def scenario_pseudo_solve(ctx, grid, rank, world, mb):
     s.close()
 
 
+def scenario_cshim(ctx, grid, rank, world, cplx, mb):
+    """The distributed C entry points (interface/chase_c_interface.h:61-65,95-99,126-128,149,177-195) in their grid-handle
+    form: p?chase_init[_blockcyclic]_hip_ with the caller's HOST blocks, p?chase_, p?chase_get_eigenpairs_,
+    p?chase_wrtHam_ / p?chase_readHam_ (shards <-> one raw column-major file), 'A' restart, p?chase_finalize_."""
+    import ctypes as C
+    import tempfile
+    from chase_amd.capi import lib
+    N, nev, nex = 300, 24, 16
+    H = O.clement(N, cplx)
+    dt = np.complex128 if cplx else np.float64
+    rl, cl = cd.Layout(N, mb, grid.nprow), cd.Layout(N, mb, grid.npcol)
+    Hloc = cd.local_block_of(H, rl, cl, grid.myrow, grid.mycol)
+    m, n = Hloc.shape
+    V = np.zeros((m, nev + nex), dtype=dt, order="F")
+    ritzv = np.zeros(nev + nex)
+    I = lambda v: C.byref(C.c_int(v))
+    init = C.c_int(0)
+    p = "pz" if cplx else "pd"
+    lib.chase_hip_cshim_use_ctx(C.c_void_p(ctx.h.value), 0)
+    if mb:
+        getattr(lib, p + "chase_init_blockcyclic_hip_")(I(N), I(nev), I(nex), I(mb), I(mb), C.c_void_p(Hloc.ctypes.data), I(m),
+                                                         C.c_void_p(V.ctypes.data), C.c_void_p(ritzv.ctypes.data), I(0), I(0),
+                                                         C.c_void_p(grid.h.value), C.byref(init))
+    else:
+        getattr(lib, p + "chase_init_hip_")(I(N), I(nev), I(nex), I(m), I(n), C.c_void_p(Hloc.ctypes.data), I(m),
+                                             C.c_void_p(V.ctypes.data), C.c_void_p(ritzv.ctypes.data),
+                                             C.c_void_p(grid.h.value), C.byref(init))
+    assert init.value == 1, lib.chase_hip_last_error()
+    deg, tol = C.c_int(20), C.c_double(1e-10)
+    solve = getattr(lib, p + "chase_")
+    solve(C.byref(deg), C.byref(tol), C.c_char(b"R"), C.c_char(b"S"), C.c_char(b"C"))
+    k = O.OracleCPU(H, nev, nex)
+    O.solve(k)
+    assert np.max(np.abs(ritzv[:nev] - k.ritzv[:nev])) < 1e-8
+
+    def gathered(block):
+        objs = [None] * world
+        dist.all_gather_object(objs, (grid.myrow, grid.mycol, block))
+        full = np.zeros((N, block.shape[1]), dtype=dt)
+        for (i, j, b) in objs:
+            if j == 0:
+                full[rl.globals_of(i), :] = b
+        return full
+
+    assert np.max(O.residuals(H, ritzv[:nev], gathered(V[:, :nev]))) < 1e-8             # the caller's V block was written
+    out = np.zeros((m + 3, nev), dtype=dt, order="F")
+    lam = np.zeros(nev)
+    getattr(lib, p + "chase_get_eigenpairs_")(C.c_void_p(out.ctypes.data), I(m + 3), C.c_void_p(lam.ctypes.data))
+    assert np.array_equal(out[:m, :], V[:, :nev]) and np.array_equal(lam, ritzv[:nev])
+    # restart from the converged vectors ('A'): stays converged, same eigenvalues
+    lam0 = ritzv[:nev].copy()
+    solve(C.byref(deg), C.byref(tol), C.c_char(b"A"), C.c_char(b"S"), C.c_char(b"C"))
+    assert np.max(np.abs(ritzv[:nev] - lam0)) < 1e-8
+    # shards -> one raw column-major file (every rank writes its byte ranges) -> shards
+    path = os.path.join(tempfile.gettempdir(), f"chase_cshim_{os.environ.get('MASTER_PORT', '0')}.bin")
+    if rank == 0 and os.path.exists(path):
+        os.remove(path)
+    dist.barrier()
+    getattr(lib, p + "chase_wrtHam_")(path.encode())
+    dist.barrier()
+    assert np.array_equal(np.fromfile(path, dtype=dt).reshape((N, N), order="F"), H)
+    dist.barrier()
+    if rank == 0:
+        (2.0 * H).T.copy().tofile(path)               # column-major file of 2 H
+    dist.barrier()
+    getattr(lib, p + "chase_readHam_")(path.encode())
+    solve(C.byref(deg), C.byref(tol), C.c_char(b"R"), C.c_char(b"S"), C.c_char(b"C"))
+    assert np.max(np.abs(ritzv[:nev] - 2.0 * k.ritzv[:nev])) < 1e-7                       # the matrix on the device is 2 H now
+    flag = C.c_int(7)
+    getattr(lib, p + "chase_finalize_")(C.byref(flag))
+    assert flag.value == 0 and not lib.chase_hip_cshim_dist_solver(int(cplx))
+    dist.barrier()
+    if rank == 0:
+        os.remove(path)
+
+
+def scenario_p2p(ctx, grid, rank, world):
+    """chase_hip_grid_sendrecv (grid/nccl_utils.hpp:271) as a ring shift inside the row and the column group, the exact
+    maximum of chase_hip_grid_agree_max, and the transport query."""
+    import ctypes as C
+    from chase_amd.capi import lib
+    for group, size, me in ((cd.ROW, grid.npcol, grid.mycol), (cd.COL, grid.nprow, grid.myrow)):
+        n = 1000 + 7 * me
+        send = ctx.array(np.full((1000 + 7 * me, 1), float(100 * rank + me)))
+        left, right = (me - 1) % size, (me + 1) % size
+        recv = ctx.empty((1000 + 7 * left, 1), np.float64)
+        grid.sendrecv(group, send, right, recv, left)
+        got = recv.download()
+        src_rank = (grid.myrow + left * grid.nprow) if group == cd.ROW else (left + grid.mycol * grid.nprow)
+        assert np.all(got == float(100 * src_rank + left)), (group, rank, got[:3])
+    v = C.c_int(0 if rank != world - 1 else 42)
+    lib.chase_hip_grid_agree_max.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    assert lib.chase_hip_grid_agree_max(grid.h, C.byref(v)) == 0
+    assert v.value == 42
+    v = C.c_int(rank + 1)
+    assert lib.chase_hip_grid_agree_max(grid.h, C.byref(v)) == 0 and v.value == world      # a real max, not a mean
+    is_rccl, r, c = grid.transport_info()
+    assert (r, c) == ((grid.npcol, grid.nprow) if not is_rccl or os.environ.get("CHASE_HIP_RCCL_FORCE") else (1, 1)) or is_rccl
+
+
 def main():
     transport, scen = sys.argv[1], sys.argv[2]
     ctx, grid, rank, world = setup(transport)
@@ -402,6 +502,10 @@ def main():
             scenario_qr_fixtures(ctx, grid, rank, world, sys.argv[3] == "z")
         elif scen == "symcheck":
             scenario_symcheck(ctx, grid, rank, world, sys.argv[3] == "z", int(sys.argv[4]))
+        elif scen == "cshim":
+            scenario_cshim(ctx, grid, rank, world, sys.argv[3] == "z", int(sys.argv[4]))
+        elif scen == "p2p":
+            scenario_p2p(ctx, grid, rank, world)
         elif scen == "pseudo_ops":
             scenario_pseudo_ops(ctx, grid, rank, world, int(sys.argv[3]))
         elif scen == "pseudo_solve_real":

@@ -15,10 +15,28 @@ def _declared(header):
 def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(ROOT, "chase_amd", "lib", "libchase_hip.so"))
     names = _declared("chase_hip.h") + _declared("chase_hip_solver.h") + _declared("chase_hip_grid.h")
-    names += ["dchase_init_", "dchase_", "dchase_finalize_", "zchase_init_", "zchase_", "zchase_finalize_"]
-    assert len(names) > 50
+    # every entry point of the application-facing C interface (sequential, distributed grid-handle forms, helpers)
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "chase_c_interface.h")).read(), flags=re.S)
+    cnames = sorted(set(re.findall(r"\b(p?[dz]?chase_[A-Za-z0-9_]*)\s*\(", txt)))
+    assert len(cnames) >= 30 and "pzchase_init_blockcyclic_hip_" in cnames and "dchase_" in cnames
+    names += cnames
+    assert len(names) > 80
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
+
+
+def test_mpi_front_end_exports_the_reference_signatures():
+    """libchase_hip_mpi.so (built when mpi.h is present): the reference's own names for the distributed inits
+    (interface/chase_c_interface.h:61-65,95-99,126-128,149)"""
+    import pytest
+    path = os.path.join(ROOT, "chase_amd", "lib", "libchase_hip_mpi.so")
+    if not os.path.exists(path):
+        pytest.skip("no MPI on this box: front end not built")
+    out = os.popen(f"nm -D --defined-only {path}").read()
+    for n in ("pdchase_init_", "pdchase_init_internal_", "pzchase_init_", "pzchase_init_internal_", "pzchase_init_pseudo_",
+              "pdchase_init_blockcyclic_", "pdchase_init_blockcyclic_internal_", "pzchase_init_blockcyclic_",
+              "pzchase_init_blockcyclic_internal_", "pzchase_init_pseudo_blockcyclic_"):
+        assert f" T {n}\n" in out, n
 
 
 def test_fails_loudly_without_gpu_or_runs_on_one():

@@ -102,3 +102,56 @@ def test_distributed_run_reproduces_the_reference_example_run():
 @pytest.mark.parametrize("nranks,mb", [(4, 0), (2, 16)])
 def test_pseudo_solve_real_fixture(nranks, mb):
     run_ranks(nranks, "host", "pseudo_solve_real", mb)
+
+
+@pytest.mark.parametrize("nranks,typ,mb", [(4, "d", 0), (4, "z", 32), (2, "z", 0)])
+def test_distributed_c_entry_points(nranks, typ, mb):
+    """p?chase_init[_blockcyclic]_hip_ / p?chase_ / p?chase_get_eigenpairs_ / p?chase_wrtHam_ / readHam_ / finalize_"""
+    run_ranks(nranks, "host", "cshim", typ, mb)
+
+
+@pytest.mark.parametrize("nranks", [4, 6])
+def test_grid_sendrecv_and_exact_agree_max(nranks):
+    run_ranks(nranks, "host", "p2p")
+
+
+def test_reference_mpi_signatures_on_one_rank():
+    """libchase_hip_mpi.so: the reference's exact MPI_Comm* entry points (pzchase_init_blockcyclic_ ..., built when mpi.h is
+    found).  One MPI rank (singleton MPI_Init, no launcher) on a 1 x 1 grid: communicator split, id broadcast, grid and
+    context creation, solve, finalize releasing both."""
+    mpi_lib = os.path.join(ROOT, "chase_amd", "lib", "libchase_hip_mpi.so")
+    if not os.path.exists(mpi_lib) or not os.path.exists("/opt/conda/lib/libmpi.so.12"):
+        pytest.skip("MPI front end not built (no mpi.h / libmpi on this box)")
+    code = """
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r)
+from chase_amd.capi import lib
+from oracle import chase_oracle as O
+mpi = C.CDLL("/opt/conda/lib/libmpi.so.12", mode=C.RTLD_GLOBAL)
+assert mpi.MPI_Init(None, None) == 0
+front = C.CDLL(%r)
+world = C.c_int(0x44000000)                      # MPICH's MPI_COMM_WORLD handle
+N, nev, nex, nb = 300, 24, 16, 32
+H = O.clement(N, True)
+V = np.zeros((N, nev + nex), dtype=complex, order="F"); ritzv = np.zeros(nev + nex)
+I = lambda v: C.byref(C.c_int(v))
+init = C.c_int(0)
+front.pzchase_init_blockcyclic_(I(N), I(nev), I(nex), I(nb), I(nb), C.c_void_p(H.ctypes.data), I(N), C.c_void_p(V.ctypes.data),
+                                C.c_void_p(ritzv.ctypes.data), I(1), I(1), C.c_char_p(b"C"), I(0), I(0), C.byref(world), C.byref(init))
+assert init.value == 1, lib.chase_hip_last_error()
+deg, tol = C.c_int(20), C.c_double(1e-10)
+lib.pzchase_(C.byref(deg), C.byref(tol), C.c_char(b"R"), C.c_char(b"S"), C.c_char(b"C"))
+k = O.OracleCPU(H, nev, nex); O.solve(k)
+assert np.max(np.abs(ritzv[:nev] - k.ritzv[:nev])) < 1e-8
+assert np.max(O.residuals(H, ritzv[:nev], V[:, :nev])) < 1e-8
+flag = C.c_int(5); lib.pzchase_finalize_(C.byref(flag)); assert flag.value == 0
+# the block-layout entry point rejects a local shape that does not match the layout
+front.pzchase_init_(I(N), I(nev), I(nex), I(N - 1), I(N), C.c_void_p(H.ctypes.data), I(N), C.c_void_p(V.ctypes.data),
+                    C.c_void_p(ritzv.ctypes.data), I(1), I(1), C.c_char_p(b"R"), C.byref(world), C.byref(init))
+assert init.value == 0
+mpi.MPI_Finalize()
+print("MPI_FRONT_OK")
+""" % (ROOT, mpi_lib)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0 and "MPI_FRONT_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])

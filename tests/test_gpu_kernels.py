@@ -359,3 +359,59 @@ def test_conj_inplace(ctx):
     check(lib.chase_hip_conj(ctx.h, 33, 5, d.ptr, 33), "conj")
     assert np.array_equal(d.download(), X.conj())
 
+
+
+def _ld_matmul(A, B):
+    Ar, Ai = A.real.astype(np.longdouble), A.imag.astype(np.longdouble)
+    Br, Bi = B.real.astype(np.longdouble), B.imag.astype(np.longdouble)
+    return (Ar @ Br - Ai @ Bi), (Ar @ Bi + Ai @ Br)
+
+
+@pytest.mark.parametrize("imag_scale", [1.0, 1e-8])
+def test_three_vs_four_multiplication_accuracy(ctx, imag_scale):
+    """The filter's three-multiplication complex scheme against a long-double product, next to the
+    four-multiplication kernel (the reference's zgemm arithmetic), on generic AND on nearly real operands (the bench matrix
+    is nearly real): 3M must meet the NORMWISE bound |C - AB| <= c k eps |A||B| (entrywise in terms of the moduli), 4M the
+    componentwise-in-real-arithmetic bound on the real and on the imaginary part separately.  Also checks the switch: the
+    3M launch executes 3/4 of the model flops, the 4M launch all of them, and 3M is used in phase 1 only."""
+    from chase_amd.capi import lib, gemm_counters
+    rng = np.random.default_rng(3)
+    m, k, n = 256, 4096, 64
+    H = rng.standard_normal((m, k)) + 1j * imag_scale * rng.standard_normal((m, k))
+    V = rng.standard_normal((k, n)) + 1j * imag_scale * rng.standard_normal((k, n))
+    A, B = np.asfortranarray(H), np.asfortranarray(V)
+    Rr, Ri = _ld_matmul(A, B)
+    mod = np.abs(A) @ np.abs(B)                                           # |A||B| with complex moduli
+    re_scale = np.abs(A.real) @ np.abs(B.real) + np.abs(A.imag) @ np.abs(B.imag)
+    im_scale = np.abs(A.real) @ np.abs(B.imag) + np.abs(A.imag) @ np.abs(B.real)
+    dA, dB = ctx.array(A), ctx.array(B)
+    res = {}
+    for name, phase, on in (("4M", 1, 0), ("3M", 1, 1), ("phase2", 2, 1)):
+        lib.chase_hip_set_gemm3m(on)
+        lib.chase_hip_ctx_set_phase(ctx.h, phase)
+        try:
+            m0, e0, _ = gemm_counters(ctx, phase)
+            dC = ctx.array(np.zeros((m, n), dtype=complex, order="F"))
+            ctx.gemm("N", m, n, k, 1.0, dA.ptr, m, dB.ptr, k, 0.0, dC.ptr, m, True)
+            C = dC.download()
+            m1, e1, _ = gemm_counters(ctx, phase)
+        finally:
+            lib.chase_hip_ctx_set_phase(ctx.h, 0)
+            lib.chase_hip_set_gemm3m(1)
+        er = np.abs(C.real.astype(np.longdouble) - Rr).astype(np.float64)
+        ei = np.abs(C.imag.astype(np.longdouble) - Ri).astype(np.float64)
+        res[name] = (er, ei, (e1 - e0) / (m1 - m0))
+        assert m1 - m0 == 2.0 * 4 * m * n * k
+    # executed share of the model flops: exactly 3/4 for the 3M launch, 1 for 4M and for every product outside the filter
+    assert res["3M"][2] == 0.75 and res["4M"][2] == 1.0 and res["phase2"][2] == 1.0
+    er4, ei4, _ = res["4M"]
+    assert np.max(er4 / re_scale) < 4 * GEMM_TOL and np.max(ei4 / im_scale) < 4 * GEMM_TOL      # componentwise (4M)
+    er2, ei2, _ = res["phase2"]
+    assert np.max(er2 / re_scale) < 4 * GEMM_TOL and np.max(ei2 / im_scale) < 4 * GEMM_TOL      # RR / residual products
+    er3, ei3, _ = res["3M"]
+    assert np.max(np.hypot(er3, ei3) / mod) < 8 * GEMM_TOL                                      # normwise (3M)
+    if imag_scale < 1e-4:
+        # documents WHY 3M stays inside the filter: the tiny imaginary part inherits the real part's absolute error
+        assert np.max(ei3 / im_scale) > 100 * np.max(ei4 / im_scale)
+    for d in (dA, dB):
+        d.free()

@@ -368,3 +368,45 @@ def test_cpp_caller_of_the_impl_classes(tmp_path):
                     "-o", exe], check=True)
     p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "HELLO_WORLD_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
+
+
+def _random_phase_clement(N, seed=11):
+    """A genuinely complex Hermitian matrix with the Clement spectrum: D H D^H with a random unitary diagonal D (phases
+    uniformly on the circle), i.e. H[i,k] * exp(i(phi_i - phi_k)); real and imaginary parts are of the same size."""
+    H = O.clement(N, True, perturb=1e-6)
+    phi = np.random.default_rng(seed).uniform(0, 2 * np.pi, N)
+    d = np.exp(1j * phi)
+    return np.asfortranarray(d[:, None] * H * np.conj(d)[None, :])
+
+
+def test_three_multiplication_filter_keeps_the_solve(ctx):
+    """Full solves of a complex Hermitian matrix with random phases, N a multiple of 128 so the filter takes the
+    three-multiplication kernel: same iteration count, filtered-vector count and call sequence as with the reference's
+    four-multiplication arithmetic, eigenvalues equal to the solver tolerance, and residuals RECOMPUTED on the host
+    below the reference's 1e-8 assertion (the convergence test itself runs on four-product H V in both runs)."""
+    from chase_amd.capi import Solver, lib, gemm_counters
+    import golden_traces as G
+    N, nev, nex = 1024, 60, 36
+    H = _random_phase_clement(N)
+    runs = {}
+    for on in (1, 0):
+        lib.chase_hip_set_gemm3m(on)
+        try:
+            s = Solver(ctx, H, nev, nex)
+            m0, e0, _ = gemm_counters(ctx, 1)
+            st = s.solve(trace=True)
+            m1, e1, _ = gemm_counters(ctx, 1)
+            runs[on] = (st, s.trace(), s.ritzv[:nev].copy(), s.V[:, :nev].copy(), s.resid()[:nev].copy(), (e1 - e0) / (m1 - m0))
+            s.close()
+        finally:
+            lib.chase_hip_set_gemm3m(1)
+    (st3, tr3, lam3, V3, res3, x3), (st4, tr4, lam4, V4, res4, x4) = runs[1], runs[0]
+    assert x3 == 0.75 and x4 == 1.0                                        # the switch really selected the two kernels
+    assert st3["iterations"] == st4["iterations"] and st3["filtered_vecs"] == st4["filtered_vecs"]
+    G.assert_same_calls(tr3, tr4, 1e-6, "3M filter vs 4M filter")
+    assert np.max(np.abs(lam3 - lam4)) < 1e-9
+    assert np.max(np.abs(lam3 - (-N + 2.0 * np.arange(nev)))) < 1e-4       # Clement spectrum (1e-6 perturbation)
+    for lam, V, res in ((lam3, V3, res3), (lam4, V4, res4)):
+        assert np.max(res) <= 1e-10
+        assert np.max(O.residuals(H, lam, V)) < RESID_TOL
+        assert O.orthogonality(V) < 1e-9
