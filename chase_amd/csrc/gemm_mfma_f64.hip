@@ -86,11 +86,30 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
     return base + (b >> 3);
 }
 
+// Logical tile index -> (row panel bm, column tile bn).  Tiles are ordered in groups of GR row panels and, inside a
+// group, column tile by column tile (GR = 1: row-major order of tiles).  A run of 64 consecutive tiles - what the 32 CUs x 2
+// workgroups of one XCD hold at a time (xcd_remap gives every XCD a contiguous range) - then covers GR row panels x 64/GR
+// column tiles.  Measured at N = 65536, n = 2560 (profiles/r02_tile_order.txt): GR = 2 and 4 are 0.9 % faster than GR = 1,
+// GR = 8 is no faster and moves MORE bytes through the fabric (L2 misses: workgroups that share an H panel stay in step
+// only while they were dispatched together) - the launch is bound by MFMA issue, not by the 1.7-2.5 TB/s of L2 fills.
+// Default GR = 2 (CHASE_HIP_TILE_GROUP overrides).
+__host__ __device__ __forceinline__ void tile_coords(int t, int gm, int gn, int GR, int& bm, int& bn)
+{
+    const int gsz = GR * gn;
+    const int g = t / gsz;
+    const int first = g * GR;
+    const int rows = (gm - first < GR) ? gm - first : GR;
+    const int r = t - g * gsz;
+    bm = first + r % rows;
+    bn = r / rows;
+}
+
 struct GemmArgs {
     const double* A; const double* B; double* C;     // C may point to split-K slabs
     long lda, ldb, ldc;                              // in elements of T
     int m, n, k;
     int gm, gn;                                      // output tiles
+    int group_rows;                                  // tile order: row panels per group (1 = row-major order of tiles)
     // Work decomposition (removes wave quantisation for arbitrary active widths): blocks [0, full_tiles) own one whole
     // output tile each; the remaining tiles ("tail": fewer than one full round of the chip) are cut into tail_sk K pieces
     // of tail_kchunk each, written as raw BM x BN partial slabs and combined by tail_reduce_kernel in a fixed order.
@@ -141,7 +160,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
         raw = true;
         slab = p.slabs + (size_t)P * (BM * BN * EPT);
     }
-    const int bn = tile % p.gn, bm = tile / p.gn;
+    int bm, bn;
+    tile_coords((int)tile, p.gm, p.gn, p.group_rows, bm, bn);
     const int row0 = bm * BM, col0 = bn * BN;
     const int nkt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
 
@@ -581,12 +601,14 @@ constexpr int TAIL_PARTS = 4;
 template <bool CPLX, int BM, int BN>
 __global__ __launch_bounds__(256) void tail_reduce_kernel(const double* __restrict__ slabs, int first_tile, int sk,
                                                           int gn, int m, int n, double* __restrict__ C, long ldc,
-                                                          double are, double aim, double bre, double bim)
+                                                          double are, double aim, double bre, double bim, int group_rows)
 {
     constexpr int EPT = CPLX ? 2 : 1;
     const int tt = blockIdx.x / TAIL_PARTS, part = blockIdx.x % TAIL_PARTS;
     const int tile = first_tile + tt;
-    const int row0 = (tile / gn) * BM, col0 = (tile % gn) * BN;
+    int bm, bn;
+    tile_coords(tile, (m + BM - 1) / BM, gn, group_rows, bm, bn);
+    const int row0 = bm * BM, col0 = bn * BN;
     const double* base = slabs + (size_t)tt * sk * (BM * BN * EPT);
     const bool has_beta = (bre != 0.0) || (bim != 0.0);
     constexpr int SHARE = BM * BN / TAIL_PARTS;
@@ -656,6 +678,8 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
     GemmArgs a;
     a.A = A; a.B = B; a.C = C; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.m = m; a.n = n; a.k = k;
     a.gm = (m + C_::BM - 1) / C_::BM; a.gn = (n + C_::BN - 1) / C_::BN;
+    static const int group_rows = [] { const char* e = getenv("CHASE_HIP_TILE_GROUP"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
+    a.group_rows = group_rows;
     a.alpha_re = alpha[0]; a.alpha_im = CPLX ? alpha[1] : 0.0;
     a.beta_re = beta[0];   a.beta_im = CPLX ? beta[1] : 0.0;
     const long tiles = (long)a.gm * a.gn;
@@ -716,7 +740,7 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
     }
     if (tail > 0) {
         hipLaunchKernelGGL((tail_reduce_kernel<CPLX, C_::BM, C_::BN>), dim3((unsigned)tail * TAIL_PARTS), dim3(256), 0, st, ws,
-                           (int)full, sk, a.gn, m, n, C, ldc, a.alpha_re, a.alpha_im, a.beta_re, a.beta_im);
+                           (int)full, sk, a.gn, m, n, C, ldc, a.alpha_re, a.alpha_im, a.beta_re, a.beta_im, a.group_rows);
     }
     // flops the matrix cores execute for this product: the reference's model 2*F*m*n*k (F = 4 complex), 3/4 of it in 3M
     if (li.exec_flops) *li.exec_flops += 2.0 * (CPLX ? 4.0 : 1.0) * m * (double)n * k * ((CAN3M && ok3m) ? 0.75 : 1.0);

@@ -9,17 +9,19 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 640
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 op = sys.argv[5] if len(sys.argv) > 5 else "N"
+pad = int(sys.argv[6]) if len(sys.argv) > 6 else 0          # extra rows in the leading dimensions (set-aliasing probe)
 with Context(0) as ctx:
     dt = np.complex128 if cplx else np.float64
-    dA = ctx.empty((N, N), dt); dB = ctx.empty((N, n), dt); dC = ctx.empty((N, n), dt)
-    check(lib.chase_hip_fill_normal(ctx.h, int(cplx), N, N, dA.ptr, N, 0, 0, N, 1), "fill")
-    check(lib.chase_hip_fill_normal(ctx.h, int(cplx), N, n, dB.ptr, N, 0, 0, N, 2), "fill")
-    check(lib.chase_hip_fill_normal(ctx.h, int(cplx), N, n, dC.ptr, N, 0, 0, N, 3), "fill")
+    L = N + pad
+    dA = ctx.empty((L, N), dt); dB = ctx.empty((L, n), dt); dC = ctx.empty((L, n), dt)
+    check(lib.chase_hip_fill_normal(ctx.h, int(cplx), L, N, dA.ptr, L, 0, 0, L, 1), "fill")
+    check(lib.chase_hip_fill_normal(ctx.h, int(cplx), L, n, dB.ptr, L, 0, 0, L, 2), "fill")
+    check(lib.chase_hip_fill_normal(ctx.h, int(cplx), L, n, dC.ptr, L, 0, 0, L, 3), "fill")
     lib.chase_hip_ctx_set_phase(ctx.h, 1)
-    ctx.gemm(op, N, n, N, 0.5, dA.ptr, N, dB.ptr, N, 0.25, dC.ptr, N, cplx)
+    ctx.gemm(op, N, n, N, 0.5, dA.ptr, L, dB.ptr, L, 0.25, dC.ptr, L, cplx)
     ctx.timer_start()
     for _ in range(reps):
-        ctx.gemm(op, N, n, N, 0.5, dA.ptr, N, dB.ptr, N, 0.25, dC.ptr, N, cplx)
+        ctx.gemm(op, N, n, N, 0.5, dA.ptr, L, dB.ptr, L, 0.25, dC.ptr, L, cplx)
     ms = ctx.timer_stop() / reps
     F = 4 if cplx else 1
-    print(f"HEMM cplx={cplx} op={op} N={N} n={n}: {ms:.3f} ms {2.0*F*N*N*n/(ms*1e-3)/1e12:.2f} TFLOP/s", flush=True)
+    print(f"HEMM cplx={cplx} op={op} N={N} n={n} ld={L} tile_group={os.environ.get('CHASE_HIP_TILE_GROUP', '1')}: {ms:.3f} ms {2.0*F*N*N*n/(ms*1e-3)/1e12:.2f} TFLOP/s", flush=True)

@@ -16,6 +16,8 @@ GROUPS_=(
  "WRITE_SIZE"
  "TCC_HIT_sum TCC_MISS_sum"
 )
+# PMC_GROUPS="A B;C" overrides the default groups (semicolon separated)
+if [ -n "${PMC_GROUPS:-}" ]; then IFS=';' read -r -a GROUPS_ <<< "$PMC_GROUPS"; fi
 i=0
 for g in "${GROUPS_[@]}"; do
   d=/tmp/pmc_$i; rm -rf $d
