@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 #include "../../include/chase_hip.h"
+#include "../../include/chase_hip_grid.h"
 #include "ctx.h"
 #include "kernels.h"
 
@@ -177,6 +178,125 @@ __global__ __launch_bounds__(256) void set_identity_kernel(double* __restrict__ 
         for (int e = 0; e < ept; ++e) Q[((long)c * m + r) * ept + e] = (r == c && e == 0) ? 1.0 : 0.0;
 }
 
+// ---- row-distributed variant (chase_hip_houseqr_dist) ---------------------------------------------------------------
+// The m x n block is split by rows over the ranks of a group; rank r holds mloc rows whose position in the "stacked"
+// order (rank 0's rows, then rank 1's, ...) starts at `off`.  Column j's pivot is stacked row j.
+// partial: what one all-reduce must carry for column j of the current panel (nc = remaining panel columns):
+//   buf[0]            sum |x_i|^2 over the rows below the pivot            (x = A[:, j])
+//   buf[1..2]         alpha = x[pivot]                                      (pivot owner only)
+//   buf[3+2(c-1)..]   sum conj(x_i) a_i over the rows below the pivot      (column c = 1..nc right of j)
+//   buf[3+2nc+2(c-1)] a[pivot]                                              (pivot owner only)
+template <bool CPLX>
+__global__ __launch_bounds__(256) void dhh_partial_kernel(const double* __restrict__ A, long lda, int mloc, long off, int j,
+                                                          int nc, double* __restrict__ buf)
+{
+    __shared__ double sm[4];
+    constexpr int E = CPLX ? 2 : 1;
+    const long lp = (long)j - off;                                 // local pivot row (may lie outside [0, mloc))
+    const long lo = lp + 1 < 0 ? 0 : lp + 1;
+    const bool owner = lp >= 0 && lp < mloc;
+    const double* x = A + (long)j * lda * E;
+    const int c = blockIdx.x;
+    if (c == 0) {
+        double s = 0.0;
+        for (long i = lo * E + threadIdx.x; i < (long)mloc * E; i += 256) { const double v = x[i]; s += v * v; }
+        s = bsum256(s, sm);
+        if (threadIdx.x == 0) {
+            buf[0] = s;
+            buf[1] = owner ? x[lp * E] : 0.0;
+            buf[2] = (owner && CPLX) ? x[lp * E + 1] : 0.0;
+        }
+        return;
+    }
+    const double* a = A + (long)(j + c) * lda * E;
+    double wr = 0.0, wi = 0.0;
+    for (long i = lo + threadIdx.x; i < mloc; i += 256) {
+        if constexpr (CPLX) {
+            const double vr = x[2 * i], vi = x[2 * i + 1], ar = a[2 * i], ai = a[2 * i + 1];
+            wr += vr * ar + vi * ai;
+            wi += vr * ai - vi * ar;
+        } else wr += x[i] * a[i];
+    }
+    wr = bsum256(wr, sm);
+    if (CPLX) wi = bsum256(wi, sm);
+    if (threadIdx.x == 0) {
+        buf[3 + 2 * (c - 1)] = wr;
+        buf[3 + 2 * (c - 1) + 1] = wi;
+        buf[3 + 2 * nc + 2 * (c - 1)] = owner ? a[lp * E] : 0.0;
+        buf[3 + 2 * nc + 2 * (c - 1) + 1] = (owner && CPLX) ? a[lp * E + 1] : 0.0;
+    }
+}
+
+// update from the all-reduced buffer (every rank derives the same beta / tau / scale from the same numbers):
+//   workgroup 0: v = [0 .. 0, 1, scale * x_below] into column jj of the panel buffer Vb (mloc rows), tau[j]
+//   workgroup c: a_c -= conj(tau) (v^H a_c) v   (LAPACK xLARFG + xLARF of H^H, as house_gen / house_apply above)
+template <bool CPLX>
+__global__ __launch_bounds__(256) void dhh_update_kernel(double* __restrict__ A, long lda, int mloc, long off, int j, int nc,
+                                                         const double* __restrict__ buf, double* __restrict__ Vb, int jj,
+                                                         double* __restrict__ tau)
+{
+    constexpr int E = CPLX ? 2 : 1;
+    const long lp = (long)j - off;
+    const long lo = lp + 1 < 0 ? 0 : lp + 1;
+    const bool owner = lp >= 0 && lp < mloc;
+    const double xn2 = buf[0], ar = buf[1], ai = CPLX ? buf[2] : 0.0;
+    const bool ident = (xn2 == 0.0 && ai == 0.0);                  // H = I
+    double beta = ar, tr = 0.0, ti = 0.0, sr = 0.0, si = 0.0;
+    if (!ident) {
+        const double nrm = sqrt(ar * ar + ai * ai + xn2);
+        beta = (ar >= 0.0) ? -nrm : nrm;
+        tr = (beta - ar) / beta;
+        ti = -ai / beta;
+        const double dr = ar - beta, di = ai, den = dr * dr + di * di;
+        sr = dr / den; si = -di / den;                              // scale = 1 / (alpha - beta)
+    }
+    const double* x = A + (long)j * lda * E;
+    const int c = blockIdx.x;
+    if (c == 0) {
+        double* v = Vb + (long)jj * mloc * E;
+        for (long i = threadIdx.x; i < mloc; i += 256) {
+            double vr = 0.0, vi = 0.0;
+            if (i == lp) vr = 1.0;
+            else if (i >= lo) {
+                if constexpr (CPLX) { const double xr = x[2 * i], xi = x[2 * i + 1]; vr = xr * sr - xi * si; vi = xr * si + xi * sr; }
+                else vr = x[i] * sr;
+            }
+            v[i * E] = vr;
+            if (CPLX) v[i * E + 1] = vi;
+        }
+        if (threadIdx.x == 0) { tau[j * E] = tr; if (CPLX) tau[j * E + 1] = ti; }
+        return;
+    }
+    if (ident) return;
+    // w = v^H a = conj(scale) * (x_below^H a_below) + a[pivot];  f = conj(tau) * w
+    const double dr_ = buf[3 + 2 * (c - 1)], di_ = buf[3 + 2 * (c - 1) + 1];
+    const double pr = buf[3 + 2 * nc + 2 * (c - 1)], pi = buf[3 + 2 * nc + 2 * (c - 1) + 1];
+    const double wr = (sr * dr_ + si * di_) + pr, wi = (sr * di_ - si * dr_) + pi;
+    const double fr = tr * wr + ti * wi, fi = tr * wi - ti * wr;
+    // g = f * scale: a_below -= g * x_below
+    const double gr = fr * sr - fi * si, gi = fr * si + fi * sr;
+    double* a = A + (long)(j + c) * lda * E;
+    for (long i = lo + threadIdx.x; i < mloc; i += 256) {
+        if constexpr (CPLX) {
+            const double xr = x[2 * i], xi = x[2 * i + 1];
+            a[2 * i] -= gr * xr - gi * xi;
+            a[2 * i + 1] -= gr * xi + gi * xr;
+        } else a[i] -= gr * x[i];
+    }
+    if (owner && threadIdx.x == 0) {
+        a[lp * E] -= fr;
+        if (CPLX) a[lp * E + 1] -= fi;
+    }
+}
+
+// Q (mloc x n, ld = mloc) <- this rank's rows of the first n columns of the identity in stacked order
+__global__ __launch_bounds__(256) void set_identity_stacked_kernel(double* __restrict__ Q, int mloc, long off, int n, int ept)
+{
+    const int c = blockIdx.y;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < mloc; r += gridDim.x * 256)
+        for (int e = 0; e < ept; ++e) Q[((long)c * mloc + r) * ept + e] = (off + r == c && e == 0) ? 1.0 : 0.0;
+}
+
 } // namespace chase_hip
 
 using namespace chase_hip;
@@ -191,6 +311,11 @@ using namespace chase_hip;
     do {                                                                                                               \
         int r_ = (x);                                                                                                  \
         if (r_) return r_;                                                                                             \
+    } while (0)
+#define HIPCHK_RET(x)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e_ = (x);                                                                                           \
+        if (e_ != hipSuccess) return hip_fail(e_, #x);                                                                 \
     } while (0)
 
 static int g3(chase_hip_ctx* c, bool cplx, char op, int m, int n, int k, double ar, const double* A, long lda,
@@ -311,6 +436,96 @@ extern "C" int chase_hip_houseqr(chase_hip_ctx* c, int cplx_, int m, int n, void
         return 0;
     };
     rc = body();
+    hipStreamSynchronize(st);
+    hipFree(blk);
+    return rc;
+}
+
+
+/* Householder QR of a ROW-DISTRIBUTED m x n block (m = sum of the ranks' mloc >= n): V_loc <- this rank's rows of the first
+ * n columns of Q.  Replaces the reference's distributed Householder (linalg/internal/mpi/householder_qr.hpp:99-223 panel
+ * factorisation, :772-1054 blocked compact-WY + form Q, :1057-1417 block-cyclic rows; NCCL twin nccl/householder_qr.hpp:2957).
+ * Differences by design: the pivot of column j is row j of the STACKED order (rank 0's rows first; `row_offset` = number of
+ * rows held by the lower-ranked members), which makes block and block-cyclic row layouts the same code - Q then spans the
+ * same nested column spaces as the reference's, with columns that may differ by a phase; every column costs ONE fused
+ * all-reduce (|x|^2, alpha, x^H A_panel and the pivot row together) instead of three, every panel one more (V^H [V | C]),
+ * all scalars stay on the device.  No buffer is larger than the local block. */
+extern "C" int chase_hip_houseqr_dist(chase_hip_ctx* c, chase_hip_grid* grid, int group, int cplx_, int mloc, int n, void* V_,
+                                      long ldv, long row_offset)
+{
+    if (!c || !grid || (!V_ && mloc > 0)) return set_error(CHASE_HIP_EINVAL, "houseqr_dist: NULL argument");
+    (void)hipSetDevice(c->device);
+    if (mloc < 0 || n < 0 || ldv < mloc || row_offset < 0) return set_error(CHASE_HIP_EINVAL, "houseqr_dist: bad shape");
+    if (n == 0) return 0;
+    const bool cplx = cplx_ != 0;
+    const int E = cplx ? 2 : 1;
+    double* A = (double*)V_;
+    hipStream_t st = c->stream;
+    const int npan = (n + HNB - 1) / HNB;
+    const int ml = mloc > 0 ? mloc : 1;                              // keep leading dimensions valid on an empty rank
+    // scratch: Q (mloc x n) | Vb (mloc x nb) | Wr (nb x (nb + n)) | W2 (nb x n) | T (npan x nb x nb) | tau (n) | buf
+    const size_t szQ = (size_t)ml * n * E, szV = (size_t)ml * HNB * E, szWr = (size_t)HNB * (HNB + n) * E;
+    const size_t szW2 = (size_t)HNB * n * E, szT = (size_t)npan * HNB * HNB * E, szTau = (size_t)n * E;
+    const size_t szBuf = 3 + 4 * (size_t)HNB + 8;
+    double* blk = nullptr;
+    if (hipMalloc((void**)&blk, (szQ + szV + szWr + szW2 + szT + szTau + szBuf) * sizeof(double)) != hipSuccess)
+        return set_error(CHASE_HIP_ENOMEM, "houseqr_dist: scratch allocation failed");
+    double* Q = blk; double* Vb = Q + szQ; double* Wr = Vb + szV; double* W2 = Wr + szWr; double* T = W2 + szW2;
+    double* tau = T + szT; double* buf = tau + szTau;
+    auto body = [&]() -> int {
+        for (int p = 0; p < npan; ++p) {
+            const int j0 = p * HNB, nb = (n - j0 < HNB) ? n - j0 : HNB, pend = j0 + nb;
+            for (int j = j0; j < pend; ++j) {
+                const int nc = pend - j - 1;
+                if (cplx) KL(hipLaunchKernelGGL(dhh_partial_kernel<true>, dim3(1 + nc), dim3(256), 0, st, A, ldv, mloc, row_offset, j, nc, buf));
+                else      KL(hipLaunchKernelGGL(dhh_partial_kernel<false>, dim3(1 + nc), dim3(256), 0, st, A, ldv, mloc, row_offset, j, nc, buf));
+                RC(chase_hip_grid_allreduce(grid, group, buf, (size_t)(3 + 4 * nc), 0));
+                if (cplx) KL(hipLaunchKernelGGL(dhh_update_kernel<true>, dim3(1 + nc), dim3(256), 0, st, A, ldv, mloc, row_offset, j, nc, buf, Vb, j - j0, tau));
+                else      KL(hipLaunchKernelGGL(dhh_update_kernel<false>, dim3(1 + nc), dim3(256), 0, st, A, ldv, mloc, row_offset, j, nc, buf, Vb, j - j0, tau));
+            }
+            // one all-reduce for G = V^H V (-> T) and W = V^H C of the trailing columns
+            const int nt = n - pend;
+            RC(g3(c, cplx, 'C', nb, nb, mloc, 1.0, Vb, ml, Vb, ml, 0.0, Wr, nb));
+            double* W1 = Wr + (size_t)nb * nb * E;
+            if (nt > 0) RC(g3(c, cplx, 'C', nb, nt, mloc, 1.0, Vb, ml, A + (long)pend * ldv * E, ldv, 0.0, W1, nb));
+            if (mloc == 0) HIPCHK_RET(hipMemsetAsync(Wr, 0, (size_t)nb * (nb + nt) * E * sizeof(double), st));
+            RC(chase_hip_grid_allreduce(grid, group, Wr, (size_t)nb * (nb + nt) * E, 0));
+            double* Tp = T + (size_t)p * HNB * HNB * E;
+            if (cplx) KL(hipLaunchKernelGGL(larft_kernel<true>, dim3(1), dim3(64), 0, st, Wr, nb, tau + (size_t)j0 * E, Tp));
+            else      KL(hipLaunchKernelGGL(larft_kernel<false>, dim3(1), dim3(64), 0, st, Wr, nb, tau + (size_t)j0 * E, Tp));
+            if (nt > 0) {                                            // C -= V T^H (V^H C)
+                RC(g3(c, cplx, 'C', nb, nt, nb, 1.0, Tp, HNB, W1, nb, 0.0, W2, nb));
+                RC(g3(c, cplx, 'N', mloc, nt, nb, -1.0, Vb, ml, W2, nb, 1.0, A + (long)pend * ldv * E, ldv));
+            }
+            // the factored columns are dead (R is not needed): they become the store of the panel's reflectors
+            if (mloc > 0) {
+                int e = copy2d(st, Vb, (long)ml * E, A + (long)j0 * ldv * E, ldv * E, (long)mloc * E, nb);
+                if (e) return hip_fail((hipError_t)e, "houseqr_dist: reflector store");
+            }
+        }
+        // ---- Q = H_0 ... H_{n-1} I(:, 0:n): backward accumulation, one all-reduce per panel ----
+        {
+            unsigned gx = (unsigned)((ml + 1023) / 1024); if (gx > 64) gx = 64; if (gx < 1) gx = 1;
+            KL(hipLaunchKernelGGL(set_identity_stacked_kernel, dim3(gx, n), dim3(256), 0, st, Q, mloc, row_offset, n, E));
+        }
+        for (int p = npan - 1; p >= 0; --p) {
+            const int j0 = p * HNB, nb = (n - j0 < HNB) ? n - j0 : HNB, nq = n - j0;
+            const double* Vp = A + (long)j0 * ldv * E;               // stored reflectors (zeros above the pivots included)
+            double* Qs = Q + (long)j0 * ml * E;
+            RC(g3(c, cplx, 'C', nb, nq, mloc, 1.0, Vp, ldv, Qs, ml, 0.0, Wr, nb));
+            if (mloc == 0) HIPCHK_RET(hipMemsetAsync(Wr, 0, (size_t)nb * nq * E * sizeof(double), st));
+            RC(chase_hip_grid_allreduce(grid, group, Wr, (size_t)nb * nq * E, 0));
+            double* Tp = T + (size_t)p * HNB * HNB * E;
+            RC(g3(c, cplx, 'N', nb, nq, nb, 1.0, Tp, HNB, Wr, nb, 0.0, W2, nb));
+            RC(g3(c, cplx, 'N', mloc, nq, nb, -1.0, Vp, ldv, W2, nb, 1.0, Qs, ml));
+        }
+        if (mloc > 0) {
+            int e = copy2d(st, Q, (long)ml * E, A, ldv * E, (long)mloc * E, n);
+            if (e) return hip_fail((hipError_t)e, "houseqr_dist: copy-back");
+        }
+        return 0;
+    };
+    const int rc = body();
     hipStreamSynchronize(st);
     hipFree(blk);
     return rc;

@@ -21,7 +21,8 @@
 //     panel p's all-reduce (the reference left this as commented-out code, linalg/internal/nccl/hemm.hpp:97-288);
 //   * host control flow (potrf info, Ritz values, residuals) is made identical on all ranks by tiny agreement
 //     collectives instead of relying on bitwise-identical replicas;
-//   * Swap() is deferred into one column permutation, Lanczos scalars stay on the device.
+//   * Swap() is deferred into one column permutation, Lanczos scalars stay on the device;
+//   * the Householder fallback pivots in the stacked row order and fuses each column's three scalar all-reduces into one.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -578,28 +579,15 @@ protected:
         return info;
     }
 
-    // Householder fallback: gather the full N x nevex block inside the column group, factor it redundantly with the
-    // single-GPU blocked Householder kernel set, keep the local rows.
+    // Householder fallback on the row-distributed block (mpi/householder_qr.hpp:737-1417, nccl/householder_qr.hpp:2957):
+    // blocked compact-WY panel factorisation inside the column group, pivots in the stacked row order (block and
+    // block-cyclic layouts alike), one fused all-reduce per column and two per panel; nothing larger than m_loc x n.
     void householder()
     {
         last_qr_variant_ = 0;
-        T* full = nullptr;
-        int rc = chase_hip_malloc(ctx_, (void**)&full, N_ * nc_ * sizeof(T));
-        if (rc) throw HipStatusError(rc, "householder workspace");
-        try {
-            for (int ip = 0; ip < nprow_; ++ip) {
-                const int cnt = rowmap_cnt_[ip];
-                if (cnt == 0) continue;
-                if (ip == myrow_)
-                    hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)nc_, dV1_, (long)m_, dStage_, (long)m_), "lacpy");
-                coll(chase_hip_grid_bcast(grid_, CHASE_HIP_COL, dStage_, (std::size_t)cnt * nc_ * E, ip, 0));
-                hip_ok(chase_hip_rows_indexed(ctx_, CP, dStage_, cnt, full, (long)N_, d_rowmap_[ip], cnt, (int)nc_, 1), "scatter");
-            }
-            hip_ok(chase_hip_houseqr(ctx_, CP, (int)N_, (int)nc_, full, (long)N_), "houseqr");
-            hip_ok(chase_hip_rows_indexed(ctx_, CP, full, (long)N_, dV1_, (long)m_, d_rowmap_[myrow_], (int)m_, (int)nc_, 0), "gather");
-            hip_ok(chase_hip_ctx_sync(ctx_), "sync");
-        } catch (...) { chase_hip_free(ctx_, full); throw; }
-        chase_hip_free(ctx_, full);
+        long off = 0;
+        for (int q = 0; q < myrow_; ++q) off += Rr_.count(q);
+        coll(chase_hip_houseqr_dist(ctx_, grid_, CHASE_HIP_COL, CP, (int)m_, (int)nc_, dV1_, (long)m_, off));
     }
 
     void reset_perm() { for (std::size_t i = 0; i < nc_; ++i) perm_[i] = (int)i; perm_dirty_ = false; }

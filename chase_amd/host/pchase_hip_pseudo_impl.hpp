@@ -11,7 +11,7 @@
 //   Resd                       Impl/pchase_cpu/pchase_cpu.hpp:903-915 (mpi/residuals.hpp with the pseudo product)
 //   Lanczos (S inner product)  linalg/internal/mpi/pseudo_hermitian_lanczos.hpp:57-470
 // Everything that is layout plumbing (redistribution, packed Gram all-reduce, agreement collectives, CholQR, the
-// gather-based Householder fallback, deferred Swap) is inherited from pChaseHip; the sign flips act on the rows whose
+// distributed Householder fallback, deferred Swap) is inherited from pChaseHip; the sign flips act on the rows whose
 // GLOBAL index is >= N/2, so block and block-cyclic layouts are both covered.
 #pragma once
 #include "pchase_hip_impl.hpp"
@@ -36,12 +36,8 @@ public:
         this->alloc((void**)&dG_, this->m_ * this->n_ * sizeof(T));       // S H_loc S, rebuilt from H_loc at every initVecs
         this->dHbac_ = dG_; this->ldhbac_ = this->m_;
         build_g();
-        this->alloc((void**)&dFull_, N * this->nevex_ * sizeof(T));
         this->alloc((void**)&dScal_, 4096);
-        std::vector<int> km(this->m_);                       // K-conjugation partner (global row) of every local row
-        for (std::size_t l = 0; l < this->m_; ++l)
-            km[l] = (int)((this->Rr_.global((long)l, this->myrow_) + (long)(N / 2)) % (long)N);
-        d_kmap_ = this->upload_ints(km);
+        build_kconj_exchange();
     }
 
     bool isSym() override { return false; }
@@ -99,27 +95,36 @@ public:
     }
 
     // second half [nc - locked - block, nc - locked) = K-conjugate of the first half [locked, locked + block):
-    // second[g, j] = conj(first[(g + N/2) mod N, j]).  The partner rows live on other grid rows: gather the first-half
-    // block inside the column group (one broadcast per grid row), then pick the partner of every local row.
+    // second[g, j] = conj(first[(g + N/2) mod N, j]).  The partner rows live on other grid rows: pairwise exchange inside
+    // the column group like the reference's MPI_Sendrecv / ncclSendrecvWrapper pairs (distMultiVector.hpp:1879-2060,
+    // grid/nccl_utils.hpp:271) - step s sends the rows whose partner lives s grid rows further to that rank and receives
+    // from the rank s rows back; N even makes the row pairing an involution, so the two lists of a pair match.
     void ApplyKconjugate(std::size_t block) override
     {
         this->flush_swaps(); this->sync_comm();
         if (block == 0) return;
         if (block > this->nevex_) throw std::invalid_argument("ApplyKconjugate: block larger than nev+nex");
-        const std::size_t m = this->m_, N = this->N_;
+        const std::size_t m = this->m_;
         const std::size_t c2 = this->nc_ - this->locked_ - block;
         T* first = this->dV1_ + this->locked_ * m;
         T* second = this->dV1_ + c2 * m;
-        for (int ip = 0; ip < this->nprow_; ++ip) {
-            const int cnt = this->rowmap_cnt_[ip];
-            if (cnt == 0) continue;
-            if (ip == this->myrow_)
-                hip_ok(chase_hip_lacpy(this->ctx_, CP, (int)m, (int)block, first, (long)m, this->dStage_, (long)m), "lacpy");
-            P::coll(chase_hip_grid_bcast(this->grid_, CHASE_HIP_COL, this->dStage_, (std::size_t)cnt * block * E, ip, 0));
-            hip_ok(chase_hip_rows_indexed(this->ctx_, CP, this->dStage_, cnt, dFull_, (long)N, this->d_rowmap_[ip], cnt,
-                                          (int)block, 1), "scatter");
+        const int p = this->nprow_, me = this->myrow_;
+        for (int s = 0; s < p; ++s) {
+            const int to = (me + s) % p, from = (me - s + p) % p;
+            const KX& snd = kx_[to];
+            const KX& rcv = kx_[from];
+            if (snd.send_cnt)
+                hip_ok(chase_hip_rows_indexed(this->ctx_, CP, first, (long)m, this->dStage_, snd.send_cnt, snd.d_send, snd.send_cnt,
+                                              (int)block, 0), "kconj pack");
+            T* rbuf = (s == 0) ? this->dStage_ : dRecv_;
+            if (s != 0)
+                P::coll(chase_hip_grid_sendrecv(this->grid_, CHASE_HIP_COL, this->dStage_, (std::size_t)snd.send_cnt * block * E,
+                                                snd.send_cnt ? to : -1, dRecv_, (std::size_t)rcv.recv_cnt * block * E,
+                                                rcv.recv_cnt ? from : -1));
+            if (rcv.recv_cnt)
+                hip_ok(chase_hip_rows_indexed(this->ctx_, CP, rbuf, rcv.recv_cnt, second, (long)m, rcv.d_recv, rcv.recv_cnt,
+                                              (int)block, 1), "kconj unpack");
         }
-        hip_ok(chase_hip_rows_indexed(this->ctx_, CP, dFull_, (long)N, second, (long)m, d_kmap_, (int)m, (int)block, 0), "kconj");
         if (CP) hip_ok(chase_hip_conj(this->ctx_, (int)m, (int)block, second, (long)m), "conj");
         hip_ok(chase_hip_lacpy(this->ctx_, CP, (int)m, (int)block, second, (long)m, this->dV2_ + c2 * m, (long)m), "lacpy");
     }
@@ -330,9 +335,36 @@ private:
     }
 
     T* dG_ = nullptr;
-    T* dFull_ = nullptr;
+    // K-conjugate exchange lists per member q of my column group: my local rows whose partner row lives on q (sent in
+    // ascending local order), and for q's rows whose partner is mine (in q's ascending local order) my local row of that partner
+    struct KX { int send_cnt = 0, recv_cnt = 0; int* d_send = nullptr; int* d_recv = nullptr; };
+    std::vector<KX> kx_;
+    T* dRecv_ = nullptr;
+    void build_kconj_exchange()
+    {
+        const long N = (long)this->N_, half = N / 2;
+        const int p = this->nprow_, me = this->myrow_;
+        kx_.assign((std::size_t)p, KX());
+        std::size_t max_recv = 1;
+        for (int q = 0; q < p; ++q) {
+            std::vector<int> snd, rcv;
+            for (long l = 0; l < this->Rr_.count(me); ++l) {
+                const long partner = (this->Rr_.global(l, me) + half) % N;
+                if (this->Rr_.owner(partner) == q) snd.push_back((int)l);
+            }
+            for (long l = 0; l < this->Rr_.count(q); ++l) {
+                const long partner = (this->Rr_.global(l, q) + half) % N;
+                if (this->Rr_.owner(partner) == me) rcv.push_back((int)this->Rr_.local(partner));
+            }
+            kx_[(std::size_t)q].send_cnt = (int)snd.size();
+            kx_[(std::size_t)q].recv_cnt = (int)rcv.size();
+            if (!snd.empty()) kx_[(std::size_t)q].d_send = this->upload_ints(snd);
+            if (!rcv.empty()) kx_[(std::size_t)q].d_recv = this->upload_ints(rcv);
+            max_recv = std::max(max_recv, rcv.size());
+        }
+        this->alloc((void**)&dRecv_, max_recv * this->nevex_ * sizeof(T));
+    }
     void* dScal_ = nullptr;
-    int* d_kmap_ = nullptr;
 };
 
 } // namespace chase_amd

@@ -69,6 +69,15 @@ int chase_hip_grid_comm_exposed_ms(chase_hip_grid* g, double* ms, unsigned long 
  * (ncclCommCount; 1 for a group without communicator) */
 int chase_hip_grid_transport(chase_hip_grid* g, int* is_rccl, int* row_ranks, int* col_ranks);
 
+/* Householder QR of a row-distributed block inside `group`: V_loc (mloc x n, ldv) <- this rank's rows of the first n
+ * columns of Q, V = Q R over all the group's rows (their total must be >= n).  row_offset = rows held by the members with
+ * a lower group rank (the pivot of column j is row j of that stacked order; block and block-cyclic row layouts alike).
+ * Replaces cpu_distributed_houseQR_formQ / houseQR1_formQ (linalg/internal/mpi/householder_qr.hpp:737-1417,
+ * nccl/householder_qr.hpp:2957): one fused all-reduce per column, two per panel, scalars on the device, no buffer larger
+ * than the local block. */
+int chase_hip_houseqr_dist(chase_hip_ctx* ctx, chase_hip_grid* g, int group, int cplx, int mloc, int n, void* V, long ldv,
+                           long row_offset);
+
 /* ---- layout helpers (pure host arithmetic, no GPU needed) ------------------------------------------------------ */
 long chase_hip_block_len(long n, int nprocs);                      /* distMatrix.hpp:2000-2007 */
 long chase_hip_numroc(long n, long nb, int iproc, int nprocs);     /* distMatrix.hpp:44-67 (isrcproc = 0) */

@@ -201,7 +201,7 @@ def scenario_symcheck(ctx, grid, rank, world, cplx, mb):
         s.close()
 
 
-def scenario_qr_fixtures(ctx, grid, rank, world, cplx):
+def scenario_qr_fixtures(ctx, grid, rank, world, cplx, mb=0):
     """Distributed QR on the reference's own conditioned fixtures (tests/linalg/internal/mpi/cholqr.cpp,
     householder_qr.cpp; 100 x 50, cond 10 / 1e4 / ill): CholQR1 / CholQR2 / shifted CholQR2 selected by the condition
     estimate like pChASECPU::QR, potrf failure falling through to Householder, and the Householder path itself."""
@@ -209,13 +209,15 @@ def scenario_qr_fixtures(ctx, grid, rank, world, cplx):
     import conftest
     N, n = 100, 50
     pre = "matrix_cdouble_" if cplx else "matrix_double_"
-    rl, cl = cd.Layout(N, 0, grid.nprow), cd.Layout(N, 0, grid.npcol)
+    rl, cl = cd.Layout(N, mb, grid.nprow), cd.Layout(N, mb, grid.npcol)
     rows = rl.globals_of(grid.myrow)
     dH = ctx.array(cd.local_block_of(np.eye(N, dtype=np.complex128 if cplx else np.float64), rl, cl, grid.myrow, grid.mycol))
+    # the distributed Householder pivots in the stacked row order (rank 0's rows first): the permutation that undoes it
+    stacked = np.concatenate([rl.globals_of(i) for i in range(grid.nprow)])
 
     def run(name, cond, cholqr=1):
         V = conftest.read_ref_matrix(pre + name, N, n, cplx)
-        s = cd.DistSolver(ctx, grid, dH, N, n // 2, n - n // 2, cplx)
+        s = cd.DistSolver(ctx, grid, dH, N, n // 2, n - n // 2, cplx, mb, mb)
         s.set(cholqr=cholqr)
         s.Start()
         s.upload_local_V(V[rows, :]); s.initVecs(False)
@@ -229,6 +231,17 @@ def scenario_qr_fixtures(ctx, grid, rank, world, cplx):
                 Q[rl.globals_of(i), :] = blk
         s.close()
         assert np.linalg.norm(V - Q @ (Q.conj().T @ V)) <= 1e-9 * np.linalg.norm(V)       # same column space
+        if variant == 0:
+            # a QR factorisation, not just an orthonormal basis: R = Q^H V is upper triangular (nested column spans) ...
+            Rf = Q.conj().T @ V
+            assert np.linalg.norm(np.tril(Rf, -1)) <= 1e-12 * np.linalg.norm(Rf), np.linalg.norm(np.tril(Rf, -1))
+            # ... and it is THE Householder QR of the stacked-order matrix: equal to LAPACK's Q up to one phase per column
+            # (checked where Q is numerically determined: not on the ill-conditioned fixture)
+            if "ill" not in name:
+                Qs, _ = np.linalg.qr(V[stacked, :])
+                ph = np.sum(Qs.conj() * Q[stacked, :], axis=0)
+                assert np.max(np.abs(np.abs(ph) - 1)) < 1e-9
+                assert np.max(np.abs(Q[stacked, :] - Qs * ph)) < 1e-9
         return variant, O.orthogonality(Q)
 
     v, o = run("cond_10.bin", 10.0);   assert v == 1 and o <= 15 * EPS + EPS
@@ -415,7 +428,7 @@ def scenario_cshim(ctx, grid, rank, world, cplx, mb):
     assert init.value == 1, lib.chase_hip_last_error()
     deg, tol = C.c_int(20), C.c_double(1e-10)
     solve = getattr(lib, p + "chase_")
-    solve(C.byref(deg), C.byref(tol), C.c_char(b"R"), C.c_char(b"S"), C.c_char(b"C"))
+    solve(C.byref(deg), C.byref(tol), C.c_char_p(b"R"), C.c_char_p(b"S"), C.c_char_p(b"C"))
     k = O.OracleCPU(H, nev, nex)
     O.solve(k)
     assert np.max(np.abs(ritzv[:nev] - k.ritzv[:nev])) < 1e-8
@@ -436,7 +449,7 @@ def scenario_cshim(ctx, grid, rank, world, cplx, mb):
     assert np.array_equal(out[:m, :], V[:, :nev]) and np.array_equal(lam, ritzv[:nev])
     # restart from the converged vectors ('A'): stays converged, same eigenvalues
     lam0 = ritzv[:nev].copy()
-    solve(C.byref(deg), C.byref(tol), C.c_char(b"A"), C.c_char(b"S"), C.c_char(b"C"))
+    solve(C.byref(deg), C.byref(tol), C.c_char_p(b"A"), C.c_char_p(b"S"), C.c_char_p(b"C"))
     assert np.max(np.abs(ritzv[:nev] - lam0)) < 1e-8
     # shards -> one raw column-major file (every rank writes its byte ranges) -> shards
     path = os.path.join(tempfile.gettempdir(), f"chase_cshim_{os.environ.get('MASTER_PORT', '0')}.bin")
@@ -451,10 +464,11 @@ def scenario_cshim(ctx, grid, rank, world, cplx, mb):
         (2.0 * H).T.copy().tofile(path)               # column-major file of 2 H
     dist.barrier()
     getattr(lib, p + "chase_readHam_")(path.encode())
-    solve(C.byref(deg), C.byref(tol), C.c_char(b"R"), C.c_char(b"S"), C.c_char(b"C"))
+    solve(C.byref(deg), C.byref(tol), C.c_char_p(b"R"), C.c_char_p(b"S"), C.c_char_p(b"C"))
     assert np.max(np.abs(ritzv[:nev] - 2.0 * k.ritzv[:nev])) < 1e-7                       # the matrix on the device is 2 H now
     flag = C.c_int(7)
     getattr(lib, p + "chase_finalize_")(C.byref(flag))
+    lib.chase_hip_cshim_dist_solver.restype = C.c_void_p
     assert flag.value == 0 and not lib.chase_hip_cshim_dist_solver(int(cplx))
     dist.barrier()
     if rank == 0:
@@ -499,7 +513,7 @@ def main():
         elif scen == "refcounts":
             scenario_reference_run_counts(ctx, grid, rank, world)
         elif scen == "qr_fixtures":
-            scenario_qr_fixtures(ctx, grid, rank, world, sys.argv[3] == "z")
+            scenario_qr_fixtures(ctx, grid, rank, world, sys.argv[3] == "z", int(sys.argv[4]) if len(sys.argv) > 4 else 0)
         elif scen == "symcheck":
             scenario_symcheck(ctx, grid, rank, world, sys.argv[3] == "z", int(sys.argv[4]))
         elif scen == "cshim":

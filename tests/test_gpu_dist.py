@@ -79,9 +79,11 @@ def test_distributed_symmetry_check(nranks, typ, mb):
     run_ranks(nranks, "host", "symcheck", typ, mb)
 
 
-@pytest.mark.parametrize("nranks,typ", [(4, "z"), (2, "d")])
-def test_distributed_qr_on_reference_fixtures(nranks, typ):
-    run_ranks(nranks, "host", "qr_fixtures", typ)
+@pytest.mark.parametrize("nranks,typ,mb", [(4, "z", 0), (2, "d", 0), (6, "z", 0), (8, "d", 0), (4, "z", 8), (6, "d", 16), (1, "z", 0)])
+def test_distributed_qr_on_reference_fixtures(nranks, typ, mb):
+    """CholQR variants and the DISTRIBUTED Householder (panel factorisation over the row-distributed block: pivots cross
+    rank boundaries with 6 and 8 ranks, block-cyclic rows with mb > 0) on the reference's conditioned fixtures"""
+    run_ranks(nranks, "host", "qr_fixtures", typ, mb)
 
 
 def test_solve_blockcyclic_4x2_eight_ranks():
@@ -140,7 +142,7 @@ front.pzchase_init_blockcyclic_(I(N), I(nev), I(nex), I(nb), I(nb), C.c_void_p(H
                                 C.c_void_p(ritzv.ctypes.data), I(1), I(1), C.c_char_p(b"C"), I(0), I(0), C.byref(world), C.byref(init))
 assert init.value == 1, lib.chase_hip_last_error()
 deg, tol = C.c_int(20), C.c_double(1e-10)
-lib.pzchase_(C.byref(deg), C.byref(tol), C.c_char(b"R"), C.c_char(b"S"), C.c_char(b"C"))
+lib.pzchase_(C.byref(deg), C.byref(tol), C.c_char_p(b"R"), C.c_char_p(b"S"), C.c_char_p(b"C"))
 k = O.OracleCPU(H, nev, nex); O.solve(k)
 assert np.max(np.abs(ritzv[:nev] - k.ritzv[:nev])) < 1e-8
 assert np.max(O.residuals(H, ritzv[:nev], V[:, :nev])) < 1e-8
