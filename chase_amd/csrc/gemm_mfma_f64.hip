@@ -110,6 +110,7 @@ struct GemmArgs {
     int m, n, k;
     int gm, gn;                                      // output tiles
     int group_rows;                                  // tile order: row panels per group (1 = row-major order of tiles)
+    int bn_cols;                                     // column stride of the output tiles: BN, or 16 g < BN ("uniform ragged" tiling)
     // Work decomposition (removes wave quantisation for arbitrary active widths): blocks [0, full_tiles) own one whole
     // output tile each; the remaining tiles ("tail": fewer than one full round of the chip) are cut into tail_sk K pieces
     // of tail_kchunk each, written as raw BM x BN partial slabs and combined by tail_reduce_kernel in a fixed order.
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
     }
     int bm, bn;
     tile_coords((int)tile, p.gm, p.gn, p.group_rows, bm, bn);
-    const int row0 = bm * BM, col0 = bn * BN;
+    const int row0 = bm * BM, col0 = bn * p.bn_cols;
     const int nkt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
 
     const bool interior = (row0 + BM <= p.m) && (col0 + BN <= p.n);
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
     const int wcol = wn * (16 * TN);
     // ragged last column tile: 16-column groups past n carry no MFMAs (wave-uniform count, 0..TN), so a partial tile
     // costs what its valid columns cost and the freed matrix-core time goes to the co-resident workgroup
-    const int jv = RAGGED ? __builtin_amdgcn_readfirstlane(min(TN, max(0, (p.n - col0 - wcol + 15) >> 4))) : TN;
+    const int jv = RAGGED ? __builtin_amdgcn_readfirstlane(min(p.bn_cols >> 4, max(0, (p.n - col0 - wcol + 15) >> 4))) : TN;
 
     // Fragments of one 4-unit K chunk: b[j] = 16-byte unit of column tile j, a[i][.] = the two doubles of row tile i's unit
     // (complex: re, im of one element; real: the chunk's two k values s = 0, 1).
@@ -601,21 +602,22 @@ constexpr int TAIL_PARTS = 4;
 template <bool CPLX, int BM, int BN>
 __global__ __launch_bounds__(256) void tail_reduce_kernel(const double* __restrict__ slabs, int first_tile, int sk,
                                                           int gn, int m, int n, double* __restrict__ C, long ldc,
-                                                          double are, double aim, double bre, double bim, int group_rows)
+                                                          double are, double aim, double bre, double bim, int group_rows,
+                                                          int bn_cols)
 {
     constexpr int EPT = CPLX ? 2 : 1;
     const int tt = blockIdx.x / TAIL_PARTS, part = blockIdx.x % TAIL_PARTS;
     const int tile = first_tile + tt;
     int bm, bn;
     tile_coords(tile, (m + BM - 1) / BM, gn, group_rows, bm, bn);
-    const int row0 = bm * BM, col0 = bn * BN;
+    const int row0 = bm * BM, col0 = bn * bn_cols;
     const double* base = slabs + (size_t)tt * sk * (BM * BN * EPT);
     const bool has_beta = (bre != 0.0) || (bim != 0.0);
     constexpr int SHARE = BM * BN / TAIL_PARTS;
     for (int e = part * SHARE + threadIdx.x; e < (part + 1) * SHARE; e += 256) {
         const int li = e % BM, lj = e / BM;
         const int gi = row0 + li, gj = col0 + lj;
-        if (gi >= m || gj >= n) continue;
+        if (gi >= m || gj >= n || lj >= bn_cols) continue;      // columns past the tile's stride belong to the next tile
         if constexpr (CPLX) {
             double sr = 0.0, si = 0.0;
             for (int z = 0; z < sk; ++z) {
@@ -671,13 +673,16 @@ constexpr int MAX_DEVICES = 64;
 template <bool CPLX, bool OPA_C, int TAG>
 static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* alpha, const double* A, long lda,
                             const double* B, long ldb, const double* beta, double* C, long ldc,
-                            double* ws, size_t ws_bytes, int num_cu, bool allow3m, const LaunchInfo& li)
+                            double* ws, size_t ws_bytes, int num_cu, bool allow3m, const LaunchInfo& li,
+                            int bn_cols = 0)
 {
     using C_ = Cfg<CPLX, OPA_C>;
     if (m <= 0 || n <= 0) return 0;
+    if (bn_cols <= 0 || bn_cols > C_::BN) bn_cols = C_::BN;
     GemmArgs a;
     a.A = A; a.B = B; a.C = C; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.m = m; a.n = n; a.k = k;
-    a.gm = (m + C_::BM - 1) / C_::BM; a.gn = (n + C_::BN - 1) / C_::BN;
+    a.gm = (m + C_::BM - 1) / C_::BM; a.gn = (n + bn_cols - 1) / bn_cols;
+    a.bn_cols = bn_cols;
     static const int group_rows = [] { const char* e = getenv("CHASE_HIP_TILE_GROUP"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
     a.group_rows = group_rows;
     a.alpha_re = alpha[0]; a.alpha_im = CPLX ? alpha[1] : 0.0;
@@ -705,7 +710,7 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
     const unsigned grid = (unsigned)(full + tail * sk);
     const size_t lds_bytes = (size_t)C_::STAGES * C_::STAGE_UNITS * sizeof(d2_t);
     // ragged: some 16-column group of the last column tile lies entirely past n
-    const bool ragged = (a.gn * C_::BN - n) >= 16;
+    const bool ragged = (bn_cols < C_::BN) || (a.gn * C_::BN - n) >= 16;
     // the dynamic-LDS limit is a per-device function attribute: one flag per device (setting it twice is harmless, so a
     // relaxed atomic is enough for concurrent first calls)
     const int dev = (li.device >= 0 && li.device < MAX_DEVICES) ? li.device : 0;
@@ -740,11 +745,34 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
     }
     if (tail > 0) {
         hipLaunchKernelGGL((tail_reduce_kernel<CPLX, C_::BM, C_::BN>), dim3((unsigned)tail * TAIL_PARTS), dim3(256), 0, st, ws,
-                           (int)full, sk, a.gn, m, n, C, ldc, a.alpha_re, a.alpha_im, a.beta_re, a.beta_im, a.group_rows);
+                           (int)full, sk, a.gn, m, n, C, ldc, a.alpha_re, a.alpha_im, a.beta_re, a.beta_im, a.group_rows, a.bn_cols);
     }
     // flops the matrix cores execute for this product: the reference's model 2*F*m*n*k (F = 4 complex), 3/4 of it in 3M
     if (li.exec_flops) *li.exec_flops += 2.0 * (CPLX ? 4.0 : 1.0) * m * (double)n * k * ((CAN3M && ok3m) ? 0.75 : 1.0);
     return (int)hipGetLastError();
+}
+
+// "Uniform ragged" tiling of a width that is not a multiple of the tile width: instead of whole tiles + one ragged tile in
+// a second launch (which streams A once more - HBM-bound for a handful of columns), give EVERY column tile the same number
+// g < TN of 16-column groups (n = 133 complex: 3 tiles of 48 columns instead of 64 + 64 + 5).  All workgroups then skip the
+// same groups, so the matrix cores pay for ntiles * g groups and A is streamed once.  Chosen when the model says it is
+// cheaper: time per 16-column group = MFMA flops of the group at the measured kernel rate, time of a pass over A = its
+// bytes at the measured streaming rate.  Returns the tile stride in columns (0: keep whole tiles + ragged launch).
+template <bool CPLX, bool OPA_C>
+static int uniform_tile_cols(int m, int n, int k)
+{
+    using C_ = Cfg<CPLX, OPA_C>;
+    static const int mode = [] { const char* e = getenv("CHASE_HIP_UNIFORM_TILES"); return e ? atoi(e) : 1; }();
+    if (mode == 0 || (!CPLX && mode != 2)) return 0;      // measured (profiles/r02_hemm_sweep.txt): a gain for the complex kernels only
+    const int ng = (n + 15) / 16, ntiles = (ng + C_::TN - 1) / C_::TN, g = (ng + ntiles - 1) / ntiles;
+    if (g >= C_::TN) return 0;
+    const double t_group = 2.0 * (CPLX ? 3.0 : 1.0) * m * (double)k * 16.0 / 68.0e12;    // executed flops at ~68 TFLOP/s
+    const double t_pass = (double)m * k * C_::EPT * 8.0 / 4.7e12;                          // one stream over A
+    const int whole = n / C_::BN, rem_groups = (n % C_::BN + 15) / 16;
+    const double cost_split = whole * C_::TN * t_group + std::max(rem_groups * t_group, t_pass) + 10e-6;
+    const double cost_uniform = std::max((double)ntiles * g * t_group, t_pass);
+    if (mode == 2 || cost_uniform < cost_split) return 16 * g;
+    return 0;
 }
 
 // A ragged last column tile (n % BN != 0) is cheap only next to its own kind: the matrix-core arbiter favours the older
@@ -761,6 +789,9 @@ static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha,
     const int rem = n % C_::BN;
     const bool balanced = (C_::WAVES_N == 1);          // all waves span the tile width: skipped groups cost nobody
     if (balanced && n > C_::BN && rem != 0 && rem <= C_::BN - 16 && ws != nullptr) {
+        const int bnu = uniform_tile_cols<CPLX, OPA_C>(m, n, k);
+        if (bnu > 0)       // every column tile gets the same number of 16-column groups: one launch, one pass over A
+            return launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, allow3m, li, bnu);
         const int n1 = n - rem;
         int rc = launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n1, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, allow3m, li);
         if (rc) return rc;
@@ -789,7 +820,17 @@ static size_t ws_need(int m, int n, int k, int num_cu)
         return sk > 1 ? slab_bytes * (size_t)tail * sk : 0;
     };
     const int rem = n % C_::BN;
-    if (n > C_::BN && rem != 0 && rem <= C_::BN - 16) return std::max(part(n - rem), part(rem));
+    if (n > C_::BN && rem != 0 && rem <= C_::BN - 16) {
+        const int bnu = uniform_tile_cols<CPLX, OPA_C>(m, n, k);
+        if (bnu > 0) {
+            const long tiles = (long)((m + C_::BM - 1) / C_::BM) * ((n + bnu - 1) / bnu);
+            const long tail = tiles % slots;
+            if (tail == 0) return 0;
+            const int sk = choose_tail_sk(tail, slots, nkt, slab_bytes, GEMM_WS_CAP);
+            return sk > 1 ? slab_bytes * (size_t)tail * sk : 0;
+        }
+        return std::max(part(n - rem), part(rem));
+    }
     return part(n);
 }
 

@@ -24,4 +24,4 @@ with Context(0) as ctx:
         ctx.gemm(op, N, n, N, 0.5, dA.ptr, L, dB.ptr, L, 0.25, dC.ptr, L, cplx)
     ms = ctx.timer_stop() / reps
     F = 4 if cplx else 1
-    print(f"HEMM cplx={cplx} op={op} N={N} n={n} ld={L} tile_group={os.environ.get('CHASE_HIP_TILE_GROUP', '1')}: {ms:.3f} ms {2.0*F*N*N*n/(ms*1e-3)/1e12:.2f} TFLOP/s", flush=True)
+    print(f"HEMM cplx={cplx} op={op} N={N} n={n} ld={L} tile_group={os.environ.get('CHASE_HIP_TILE_GROUP', 'default')}: {ms:.3f} ms {2.0*F*N*N*n/(ms*1e-3)/1e12:.2f} TFLOP/s", flush=True)
