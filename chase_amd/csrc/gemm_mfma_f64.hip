@@ -37,7 +37,12 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 #include "kernels.h"
+
+#ifndef CHASE_M3_PIPELINE
+#define CHASE_M3_PIPELINE 1
+#endif
 
 namespace chase_hip {
 
@@ -474,9 +479,80 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                     __builtin_amdgcn_sched_barrier(0);
                     st = stn;
                 }
+            } else if constexpr (CPLX && M3 && CHASE_M3_PIPELINE) {
+                // 3M software pipeline.  192 accumulator registers leave no room for a second set of fragments, so only
+                // the A fragments (8 registers) are double-buffered; each B fragment is REFILLED IN PLACE with the next
+                // chunk's data right after the six MFMAs that were its last readers, i.e. 18 MFMAs (>1000 cycles) before
+                // it is needed again.  The barrier that publishes tile kt+1 sits between the two MFMA clusters like in the
+                // four-product loop above, and the stage of tile kt is refilled as soon as its last fragment has been read.
+                constexpr int G = C_::GLDS_PER_WAVE;
+                const int npre = min(nfull, C_::STAGES);
+                for (int t = 0; t < npre; ++t) issue();
+                if (npre == 3)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+                else if (npre == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+                else                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                auto ld_a = [&](int stage, int ch, d2_t (&a)[TM]) __attribute__((always_inline)) {
+                    const d2_t* sA = lds + stage * C_::STAGE_UNITS;
+                    const int ku = 4 * ch + q;
+                    #pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int r = wrow + 16 * i + c16;
+                        if constexpr (OPA_C) a[i] = sA[kidx(r, ku)];
+                        else                 a[i] = sA[ku * UM + r];
+                    }
+                };
+                auto ld_b = [&](int stage, int ch, int j) __attribute__((always_inline)) -> d2_t {
+                    const d2_t* sB = lds + stage * C_::STAGE_UNITS + C_::A_UNITS;
+                    return sB[kidx(wcol + 16 * j + c16, 4 * ch + q)];
+                };
+                d2_t aC[TM], aN[TM], bF[TN];
+                ld_a(0, 0, aC);
+                #pragma unroll
+                for (int j = 0; j < TN; ++j) bF[j] = ld_b(0, 0, j);
+                // one MFMA cluster on (aC, bF) while the fragments of (nstage, nch) stream in; `more`: there is a next chunk
+                auto cluster = [&](int nstage, int nch, auto more_c) __attribute__((always_inline)) {
+                    constexpr bool more = decltype(more_c)::value;
+                    double sa[TM];
+                    #pragma unroll
+                    for (int i = 0; i < TM; ++i) sa[i] = OPA_C ? aC[i].x - aC[i].y : aC[i].x + aC[i].y;
+                    if (more) ld_a(nstage, nch, aN);
+                    #pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const double sb = bF[j].x + bF[j].y;
+                        if (!RAGGED || j < jv)                                 // ragged tile: groups past n carry no MFMAs
+                        #pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(bF[j].x, aC[i].x, acc[0][j][i], 0, 0, 0);
+                            acc[1][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(bF[j].y, aC[i].y, acc[1][j][i], 0, 0, 0);
+                            acc[2][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(sb, sa[i], acc[2][j][i], 0, 0, 0);
+                        }
+                        if (more) bF[j] = ld_b(nstage, nch, j);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    #pragma unroll
+                    for (int i = 0; i < TM; ++i) aC[i] = aN[i];
+                };
+                int st = 0;
+                for (int kt = 0; kt + 1 < nfull; ++kt) {
+                    const int stn = (st + 1 == C_::STAGES) ? 0 : st + 1;
+                    cluster(st, 1, std::true_type());                          // chunk 0 of tile kt, prefetching its chunk 1
+                    if (C_::STAGES > 2 && kt + 2 < nfull) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
+                    else                                  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (kt + C_::STAGES < nfull) issue();                      // tile kt+STAGES into stage st (everybody has read it)
+                    __builtin_amdgcn_sched_barrier(0);
+                    cluster(stn, 0, std::true_type());                         // chunk 1 of tile kt, prefetching chunk 0 of tile kt+1
+                    st = stn;
+                }
+                cluster(st, 1, std::true_type());                              // last tile: nothing to publish or prefetch after it
+                __builtin_amdgcn_sched_barrier(0);
+                cluster(st, 1, std::false_type());
             } else {
-                // real (80 fragment registers next to 128 accumulator registers) and 3M (192 accumulator registers) cannot
-                // double-buffer fragments: one barrier per K step, each chunk's fragments fetched right before its MFMAs
+                // real (80 fragment registers next to 128 accumulator registers) cannot double-buffer fragments: one barrier
+                // per K step, each chunk's fragments fetched right before its MFMAs (also the 3M loop without pipelining)
                 constexpr int DEPTH = C_::STAGES - 1;
                 issue();
                 if (DEPTH > 1 && nfull > 1) issue();
