@@ -240,7 +240,9 @@ __global__ __launch_bounds__(256) void ltrd_colupd_kernel(double* __restrict__ A
             double wr = W[((long)c * n + r) * E], wi = CPLX ? W[((long)c * n + r) * E + 1] : 0.0;
             if (c == jj - 1) {
                 wr += alr * vr - ali * vi; wi += alr * vi + ali * vr;
-                W[((long)c * n + r) * E] = wr; if (CPLX) W[((long)c * n + r) * E + 1] = wi;
+                // write the finalised w back - except in row k: every workgroup reads W[k, jj-1] (raw) for cw above, and
+                // nothing after this launch reads that entry (later columns use rows > k), so it must stay raw here
+                if (r != k) { W[((long)c * n + r) * E] = wr; if (CPLX) W[((long)c * n + r) * E + 1] = wi; }
             }
             // a -= V[r,c] conj(W[k,c]) + W[r,c] conj(V[k,c])
             ar -= (vr * cw[2 * c] - vi * cw[2 * c + 1]) + (wr * cv[2 * c] - wi * cv[2 * c + 1]);
