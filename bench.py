@@ -221,6 +221,17 @@ def fullwidth_probe(s, ctx, N, cplx, nevex, three_m, reps=4):
             "algorithmic": model, "launches": int(n1 - n0), "avg_launch_ms": ms / max(int(n1 - n0), 1), "traffic": None}
 
 
+def whole_run_object(tot, world):
+    """The same per-call figures over EVERY filter HEMM call of the process so far (warm-up, timed and trailing iterations
+    of all solves, before the full-width probes): the set of launches a `rocprofv3 --kernel-trace --stats` summary of this
+    command averages over (sum of the TAG=1 kernels' time / calls)."""
+    calls = max(int(tot["hemm_calls"]), 1)
+    fs = tot["filter_ms"] * 1e-3
+    return {"launches": calls, "avg_launch_ms": tot["filter_ms"] / calls, "filter_seconds_device": fs,
+            "achieved": tot["exec"] / fs / 1e12 / world if fs > 0 else None,
+            "algorithmic": tot["model"] / fs / 1e12 / world if fs > 0 else None}
+
+
 def roofline_object(model_flops, exec_flops, filt_s, calls, world, note_extra=""):
     """roofline of the dominant kernel: EXECUTED MFMA flops / HIP-event filter time / peak, per GPU (<= 1); the rate in the
     reference's flop model (which `value` is quoted in) is `algorithmic`."""
@@ -308,6 +319,7 @@ def run_single(args):
         "device": info["name"],
         "roofline": roofline_object(model_flops, exec_flops, filt_s, calls, 1),
     }
+    out["roofline"]["whole_run"] = whole_run_object(snapshot(), 1)
     attach_traffic(out, args.workload)
     if not args.no_probe and cplx:
         # reference arithmetic (four real products per complex product, the reference's zgemm) on the same launch shape

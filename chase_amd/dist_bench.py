@@ -102,6 +102,12 @@ def run_distributed(args):
     ok = bool(np.max(resid) < 1e-8 and (spec is None or spec["ok"]))
     st = complete[-1]
     solve_s = float(np.mean([c["t_all"] for c in complete]))
+    tot = snapshot()
+    tw = torch.tensor([tot["model"], tot["exec"]], dtype=torch.float64)
+    dist.all_reduce(tw, op=dist.ReduceOp.SUM)
+    tm = torch.tensor([tot["filter_ms"]], dtype=torch.float64)
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    tot["model"], tot["exec"], tot["filter_ms"] = float(tw[0]), float(tw[1]), float(tm[0])
     out = None
     if rank == 0:
         out = {
@@ -136,6 +142,7 @@ def run_distributed(args):
             "roofline": B.roofline_object(model_flops, exec_flops, filt_s, calls, world,
                                           "; filter time includes the row/column all-reduces"),
         }
+        out["roofline"]["whole_run"] = B.whole_run_object(tot, world)
     s.close()
     grid.close()
     del dH

@@ -157,3 +157,23 @@ print("MPI_FRONT_OK")
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert p.returncode == 0 and "MPI_FRONT_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
+def test_c_mpi_application_example(tmp_path):
+    """examples/c_dist_mpi.c: an MPI program in plain C on the reference's distributed entry points (pzchase_init_, pzchase_,
+    pzchase_finalize_), built with gcc against libchase_hip_mpi.so + libchase_hip.so and run as one MPI rank (one GPU here)."""
+    import shutil
+    mpi_inc, mpi_lib = "/opt/conda/include", "/opt/conda/lib"
+    lib = os.path.join(ROOT, "chase_amd", "lib")
+    if not (os.path.exists(os.path.join(lib, "libchase_hip_mpi.so")) and os.path.exists(os.path.join(mpi_inc, "mpi.h"))
+            and shutil.which("gcc")):
+        pytest.skip("no MPI / gcc on this box")
+    exe = str(tmp_path / "c_dist_mpi")
+    subprocess.run(["gcc", "-O2", "-std=gnu11", "-I" + os.path.join(ROOT, "include"), "-I" + mpi_inc,
+                    os.path.join(ROOT, "examples", "c_dist_mpi.c"), "-L" + lib, "-lchase_hip_mpi", "-lchase_hip",
+                    os.path.join(mpi_lib, "libmpi.so"), "-Wl,--allow-shlib-undefined", "-Wl,--enable-new-dtags",
+                    "-Wl,-rpath," + lib, "-Wl,-rpath," + mpi_lib, "-lm", "-o", exe],
+                   check=True)
+    p = subprocess.run([exe, "600"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0 and "-> OK" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
