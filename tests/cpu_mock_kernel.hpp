@@ -73,6 +73,9 @@ public:
         : N_(N), nev_(nev), nex_(nex), n_(nev + nex), H_(std::move(H)), V1_(N * n_), V2_(N * n_), ritzv_(n_), resid_(n_),
           cfg_(N, nev, nex) {}
     std::vector<std::string> calls;
+    // the next problem of a sequence: H[i,i] += eps * (i mod 7)  (the reference's applications refill H in place between
+    // solves, examples/4_interface; the second solve then starts from the previous eigenvectors, mode 'A')
+    void perturb_diagonal(double eps) { for (size_t i = 0; i < N_; ++i) H_[i + i * N_] += eps * (double)(i % 7); }
     void log(const char* fmt, ...) __attribute__((format(printf, 2, 3)))
     {
         char buf[256];

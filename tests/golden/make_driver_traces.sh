@@ -8,9 +8,9 @@ REF=${REF:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)
 EXE=$(mktemp -d)/ref_driver_trace
 g++ -std=c++17 -O2 -I"$REF" -o "$EXE" "$HERE/ref_driver_trace.cpp"
-run() {   # name N nev nex deg opt perturb
+run() {   # name N nev nex deg opt perturb [seq]
     local name=$1; shift
-    { echo "# reference driver run: ref_driver_trace $* (N nev nex deg opt perturb); Clement-type matrix of tests/chase_serial_solve.cpp:52-90"
+    { echo "# reference driver run: ref_driver_trace $* (N nev nex deg opt perturb [seq]); Clement-type matrix of tests/chase_serial_solve.cpp:52-90"
       "$EXE" "$@"; } > "$HERE/driver_trace_$name.txt"
     echo "driver_trace_$name.txt: $(sed -n 2,3p "$HERE/driver_trace_$name.txt" | tr '\n' ' ')"
 }
@@ -19,3 +19,4 @@ run clement256_fix  256 24 16 20 0 0        # no degree optimisation, unperturbe
 run clement512      512 50 14 10 1 1e-6     # few extra vectors, low degree: many iterations, many swaps
 run clement1001    1001 60 40 20 1 1e-6
 run clement1200    1200 80 60 20 1 1e-6     # shape of tests/noinput.cpp problem #0
+run clement256_seq  256 24 16 16 1 1e-6 1   # two problems: random start, then the perturbed matrix in approximate mode ('A')

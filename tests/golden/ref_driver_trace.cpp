@@ -6,7 +6,8 @@
 // prints iteration count, filtered-vector count, eigenpairs and the complete sequence of virtual calls with their scalar
 // arguments.  tests/golden/make_driver_traces.sh commits the output as tests/golden/driver_trace_*.txt; no reference
 // source is copied.
-//   usage: ref_driver_trace N nev nex deg opt perturb
+//   usage: ref_driver_trace N nev nex deg opt perturb [seq]   (seq = 1: second solve of the diagonally perturbed matrix from the
+//          first solve's vectors, SetApprox(true))
 #include "algorithm/algorithm.hpp"
 #include "../cpu_mock_kernel.hpp"
 
@@ -20,6 +21,11 @@ int main(int argc, char** argv)
     k.GetConfig().SetDeg(deg);
     k.GetConfig().SetOpt(opt != 0);
     chase::Solve(&k);
+    if (argc > 7 && std::atoi(argv[7]) == 1) {
+        k.perturb_diagonal(1e-3);
+        k.GetConfig().SetApprox(true);
+        chase::Solve(&k);
+    }
     print_run(k, nev);
     return 0;
 }

@@ -12,6 +12,9 @@ CASES = {
     "clement1001": (1001, 60, 40, 20, 1, 1e-6),
     "clement1200": (1200, 80, 60, 20, 1, 1e-6),
 }
+# two-problem sequence: the first solve from random vectors, then H[i,i] += 1e-3 * (i mod 7) and a solve in approximate mode
+# from the first solve's vectors (single-vector Lanczos for the upper bound, no start-vector QR)
+SEQ_CASE = ("clement256_seq", (256, 24, 16, 16, 1, 1e-6))
 # the calls the product's driver-side trace (chase_hip_solver_trace) and the oracle's trace record as well
 CORE = ("initVecs", "QR", "Lanczos", "HEMM", "RR", "Resd", "Lock")
 _NUM = re.compile(r"^[-+]?(\d+\.?\d*|\.\d+)([eE][-+]?\d+)?$")

@@ -5,7 +5,8 @@
 // tests/cpu_mock_kernel.hpp.  tests/test_host_driver.py compiles it with g++ and compares (a) with the Python oracle on the
 // same matrix and (b) with tests/golden/driver_trace_*.txt, the runs of the REFERENCE's own driver on the same kernel.
 // The mock is never linked into libchase_hip.so.
-//   usage: host_driver_harness N nev nex deg opt [perturb]
+//   usage: host_driver_harness N nev nex deg opt [perturb [seq]]   (seq = 1: a second solve of the diagonally perturbed
+//          matrix from the first solve's vectors, approximate mode)
 #include "../chase_amd/host/algorithm.hpp"
 #include "cpu_mock_kernel.hpp"
 
@@ -24,6 +25,13 @@ int main(int argc, char** argv)
     CallTrace tr;
     tr.enabled = true;
     Algorithm<double, ChaseBase<double>>::solve(&k, &st, &tr);
+    if (argc > 7 && std::atoi(argv[7]) == 1) {
+        k.perturb_diagonal(1e-3);
+        k.GetConfig().SetApprox(true);
+        SolveStats st2;
+        Algorithm<double, ChaseBase<double>>::solve(&k, &st2, &tr);
+        st.iterations += st2.iterations; st.filtered_vecs += st2.filtered_vecs; st.locked = st2.locked;
+    }
     std::printf("locked %zu\nstats_iterations %zu\nstats_filtered_vecs %zu\n", (size_t)st.locked, (size_t)st.iterations,
                 (size_t)st.filtered_vecs);
     print_run(k, nev);

@@ -410,3 +410,31 @@ def test_three_multiplication_filter_keeps_the_solve(ctx):
         assert np.max(res) <= 1e-10
         assert np.max(O.residuals(H, lam, V)) < RESID_TOL
         assert O.orthogonality(V) < 1e-9
+
+
+def test_hip_path_two_problem_sequence_matches_the_reference_driver(ctx):
+    """tests/golden/driver_trace_clement256_seq.txt: the reference's chase::Solve on a problem, then on the diagonally perturbed
+    matrix in approximate mode (SetApprox(true): start from the previous eigenvectors).  The HIP Impl with the caller's H
+    refilled in place (the C interface's sequence contract) issues the same driver-level calls in both solves."""
+    import golden_traces as G
+    from chase_amd.capi import Solver
+    name, (N, nev, nex, deg, opt, perturb) = G.SEQ_CASE
+    want = G.load(name)
+    H = O.clement(N, False, perturb=perturb)
+    s = Solver(ctx, H, nev, nex)
+    s.set(deg=deg, opt=opt)
+    st1 = s.solve(trace=True)
+    tr = s.trace()
+    idx = np.arange(N)
+    H[idx, idx] += 1e-3 * (idx % 7)                       # the Impl uploads the caller's H again in initVecs
+    s.set(approx=1)
+    st2 = s.solve(trace=True)
+    tr += s.trace()
+    assert st1["iterations"] + st2["iterations"] == want["iterations"]
+    assert st1["filtered_vecs"] + st2["filtered_vecs"] == want["filtered_vecs"]
+    drop = lambda lines: [l for l in lines if not l.startswith("Lanczos") and l.split()[0] not in ("bounds", "filter")]
+    # 1e-4 on the scalars: the second solve's bounds come from a Lanczos run started on a converged eigenvector
+    G.assert_same_calls(drop(tr), drop(G.core(want["calls"])), 1e-4, "HIP path, two-problem sequence")
+    assert np.max(np.abs(s.ritzv[:nev] - np.array(want["lam"]))) < 1e-9
+    assert np.max(O.residuals(H, s.ritzv[:nev], s.V[:, :nev])) < RESID_TOL
+    s.close()

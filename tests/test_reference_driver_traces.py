@@ -65,6 +65,42 @@ def test_oracle_issues_the_reference_drivers_calls(name):
     assert np.max(want["res"]) < 1e-10
 
 
+def _no_lanczos(lines):
+    # approximate mode calls the single-vector overload ("Lanczos1 m" at kernel level) while the driver-level traces print
+    # the configured "Lanczos m numvec" line: compare everything else
+    return [l for l in lines if not l.startswith("Lanczos")]
+
+
+def test_sequence_of_two_problems_in_approximate_mode(harness):
+    """random start, then the diagonally perturbed matrix solved from the previous vectors (mode 'A': initVecs(false), no
+    start-vector QR, single-vector Lanczos, caller-supplied Ritz values) - the reference driver's trace of both solves"""
+    name, (N, nev, nex, deg, opt, perturb) = G.SEQ_CASE
+    want = G.load(name)
+    out = subprocess.run([harness, str(N), str(nev), str(nex), str(deg), str(opt), repr(perturb), "1"], check=True,
+                         capture_output=True, text=True, timeout=900).stdout.splitlines()
+    got = G.parse_run(out)
+    assert got["iterations"] == want["iterations"] and got["filtered_vecs"] == want["filtered_vecs"]
+    G.assert_same_calls(got["calls"], want["calls"], 1e-12, "own C++ driver, two-problem sequence")
+    assert "initVecs 0" in want["calls"] and any(c.startswith("Lanczos1 ") for c in want["calls"])
+    # oracle: the same two solves.  Tolerance 1e-4 on the scalars: the second solve's upper bound comes from a Lanczos run
+    # started on a converged eigenvector (an ill-conditioned recurrence, different in every arithmetic), and the QR condition
+    # estimate rho^deg amplifies it; the call sequence, widths, offsets and counts must still be identical
+    H = O.clement(N, False, perturb=perturb)
+    k = O.OracleCPU(H, nev, nex)
+    k.config.deg, k.config.opt = deg, bool(opt)
+    tr = []
+    so1 = O.solve(k, tr)
+    idx = np.arange(N)
+    k.H[idx, idx] += 1e-3 * (idx % 7)
+    k.config.approx = True
+    so2 = O.solve(k, tr)
+    assert so1["iterations"] + so2["iterations"] == want["iterations"]
+    assert so1["filtered_vecs"] + so2["filtered_vecs"] == want["filtered_vecs"]
+    G.assert_same_calls(_no_lanczos([t for t in tr if t.split()[0] not in ("bounds", "filter")]),
+                        _no_lanczos(G.core(want["calls"])), 1e-4, "oracle, two-problem sequence")
+    assert np.max(np.abs(k.ritzv[:nev] - np.array(want["lam"]))) < 1e-9
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference checkout (build container only)")
 def test_committed_traces_are_what_the_reference_driver_produces(tmp_path):
     exe = tmp_path / "ref_driver_trace"
