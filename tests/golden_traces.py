@@ -64,3 +64,18 @@ def assert_same_calls(got, want, rtol, what):
     assert len(got) == len(want), f"{what}: {len(got)} calls, the reference driver issued {len(want)}"
     for i, (a, b) in enumerate(zip(got, want)):
         assert same_line(a, b, rtol), f"{what}: call {i}: got '{a}', the reference driver issued '{b}'"
+
+
+REF_BIN = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "ref_driver_trace")
+
+
+def run_reference_driver(N, nev, nex, deg, opt, perturb, seq=0):
+    """Runs oracle/_ref/ref_driver_trace - the reference's own chase::Solve built from the reference sources by
+    oracle/Makefile (it travels to the GPU box with the snapshot) - and parses its output; None if it was not built."""
+    import subprocess
+    exe = os.path.normpath(REF_BIN)
+    if not os.path.exists(exe):
+        return None
+    out = subprocess.run([exe, str(N), str(nev), str(nex), str(deg), str(opt), repr(perturb), str(seq)], check=True,
+                         capture_output=True, text=True, timeout=900).stdout.splitlines()
+    return parse_run(out)

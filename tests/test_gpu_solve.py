@@ -438,3 +438,26 @@ def test_hip_path_two_problem_sequence_matches_the_reference_driver(ctx):
     assert np.max(np.abs(s.ritzv[:nev] - np.array(want["lam"]))) < 1e-9
     assert np.max(O.residuals(H, s.ritzv[:nev], s.V[:, :nev])) < RESID_TOL
     s.close()
+
+
+def test_hip_path_against_a_live_run_of_the_reference_driver(ctx):
+    """oracle/_ref/ref_driver_trace (the reference's chase::Solve compiled from the reference sources, oracle/Makefile) travels
+    to the GPU box: run it HERE on a problem that has no committed golden file and require the HIP path to issue the same
+    driver-level calls; also re-derive one committed file from it."""
+    import golden_traces as G
+    from chase_amd.capi import Solver
+    live = G.run_reference_driver(384, 30, 18, 12, 1, 1e-6)
+    if live is None:
+        pytest.skip("oracle/_ref/ref_driver_trace was not built (no reference checkout at build time)")
+    N, nev, nex, deg, opt, perturb = 384, 30, 18, 12, 1, 1e-6
+    H = O.clement(N, False, perturb=perturb)
+    s = Solver(ctx, H, nev, nex)
+    s.set(deg=deg, opt=opt)
+    st = s.solve(trace=True)
+    assert st["iterations"] == live["iterations"] and st["filtered_vecs"] == live["filtered_vecs"]
+    G.assert_same_calls([t for t in s.trace() if t.split()[0] not in ("bounds", "filter")], G.core(live["calls"]), 1e-6,
+                        "HIP path vs live reference driver")
+    assert np.max(np.abs(s.ritzv[:nev] - np.array(live["lam"]))) < 1e-9
+    s.close()
+    again = G.run_reference_driver(*G.CASES["clement256"])
+    assert again["calls"] == G.load("clement256")["calls"]

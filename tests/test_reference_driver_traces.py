@@ -114,6 +114,17 @@ def test_committed_traces_are_what_the_reference_driver_produces(tmp_path):
         assert got["calls"] == want["calls"] and got["iterations"] == want["iterations"]
 
 
+def test_oracle_ref_binary_reproduces_the_committed_traces():
+    """oracle/_ref/ref_driver_trace, built by __graft_entry__.build() / oracle/Makefile from the reference sources"""
+    if G.run_reference_driver(*G.CASES["clement256"]) is None:
+        pytest.skip("oracle/_ref not built")
+    for name in ("clement256", "clement256_fix", "clement512"):
+        got, want = G.run_reference_driver(*G.CASES[name]), G.load(name)
+        assert got["calls"] == want["calls"] and got["lam"] == want["lam"]
+    name, case = G.SEQ_CASE
+    assert G.run_reference_driver(*case, seq=1)["calls"] == G.load(name)["calls"]
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference checkout (build container only)")
 def test_impl_classes_instantiate_on_the_reference_interface(tmp_path):
     """ChaseHip / pChaseHip / ChaseHipPseudo / pChaseHipPseudo<T, chase::ChaseBase<T>, chase::ChaseConfig<T>> against the
