@@ -461,3 +461,22 @@ def test_hip_path_against_a_live_run_of_the_reference_driver(ctx):
     s.close()
     again = G.run_reference_driver(*G.CASES["clement256"])
     assert again["calls"] == G.load("clement256")["calls"]
+
+
+@pytest.mark.parametrize("cplx,N,nev,nex", [(True, 1280, 80, 48), (False, 2000, 120, 70)])
+def test_solve_is_bitwise_reproducible(ctx, cplx, N, nev, nex):
+    """Every reduction on the path has a fixed order (split-K slabs, wave-shuffle trees, partial sums re-added in index
+    order), so two solves of the same problem must agree bit for bit - Ritz values, residuals, eigenvectors, call trace.
+    A cross-workgroup race anywhere in the pipeline breaks this before it breaks convergence."""
+    from chase_amd.capi import Solver
+    H = O.clement(N, cplx)
+    runs = []
+    for rep in range(3):
+        s = Solver(ctx, H, nev, nex)
+        st = s.solve(trace=True)
+        runs.append((st["iterations"], st["filtered_vecs"], s.ritzv.copy(), s.resid().copy(), s.V.copy(), s.trace()))
+        s.close()
+    for r in runs[1:]:
+        assert r[0] == runs[0][0] and r[1] == runs[0][1] and r[5] == runs[0][5]
+        assert np.array_equal(r[2], runs[0][2]) and np.array_equal(r[3], runs[0][3]) and np.array_equal(r[4], runs[0][4])
+    assert np.max(runs[0][3][:nev]) <= 1e-10
