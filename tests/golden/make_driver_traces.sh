@@ -20,3 +20,11 @@ run clement512      512 50 14 10 1 1e-6     # few extra vectors, low degree: man
 run clement1001    1001 60 40 20 1 1e-6
 run clement1200    1200 80 60 20 1 1e-6     # shape of tests/noinput.cpp problem #0
 run clement256_seq  256 24 16 16 1 1e-6 1   # two problems: random start, then the perturbed matrix in approximate mode ('A')
+
+# function-level known answers: the reference's calc_degrees / locking / filter / lanczos (+ the pseudo-Hermitian routines) on
+# the seeded scenarios of tests/driver_function_scenarios.hpp
+EXE2=$(dirname "$EXE")/ref_driver_functions
+g++ -std=c++17 -O2 -I"$REF" -o "$EXE2" "$HERE/ref_driver_functions.cpp"
+{ echo "# reference driver routines (chase::Algorithm<double>) on tests/driver_function_scenarios.hpp: S scenario, I inputs, O outputs, C kernel calls"
+  "$EXE2"; } > "$HERE/driver_functions.txt"
+echo "driver_functions.txt: $(grep -c '^S' "$HERE/driver_functions.txt") scenarios"
