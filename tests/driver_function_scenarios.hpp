@@ -82,9 +82,27 @@ public:
     void FilterPhaseStart() override { log("FilterPhaseStart"); }
     void FilterPhaseEnd() override { log("FilterPhaseEnd"); }
     void QR(std::size_t f, double c) override { log("QR %zu %.17g", f, c); }
-    void RR(double*, std::size_t b) override { log("RR %zu", b); }
+    // whole-solve scenarios: Ritz values and residuals come from a script that ignores the vectors - column position j of
+    // the block yields eig[j] (slightly moving with the iteration) and a residual that decays geometrically at its own rate.
+    // The driver under test only ever sees these numbers, so two drivers fed the same script must make the same decisions.
+    std::vector<double> eig, r0, decay;
+    std::size_t locked_ = 0, it_ = 0;
+    void RR(double* ritzv, std::size_t b) override
+    {
+        log("RR %zu", b);
+        if (eig.empty()) return;
+        for (std::size_t i = 0; i < b; ++i) ritzv[i] = eig[locked_ + i] * (1.0 + 1e-3 / (double)(it_ + 1));
+        if (pseudo_) for (std::size_t i = 0; i < b; ++i) ritzv[b + i] = -ritzv[i];         // the K-conjugate partners
+        ++it_;
+    }
     void Sort(double*, double*, double*) override {}
-    void Resd(double*, double*, std::size_t f) override { log("Resd %zu", f); }
+    void Resd(double*, double* resid, std::size_t f) override
+    {
+        log("Resd %zu", f);
+        if (eig.empty()) return;
+        const std::size_t sub = nev_ + nex_ - locked_;
+        for (std::size_t i = 0; i < sub; ++i) resid[i] = r0[locked_ + i] * std::pow(decay[locked_ + i], (double)it_);
+    }
     void Lanczos(std::size_t m, double* ub) override { log("Lanczos1 %zu", m); *ub = upperb_script; }
     void Lanczos(std::size_t M, std::size_t nv, double* ub, double* rv, double* Tau, double* rV) override
     {
@@ -96,13 +114,13 @@ public:
     }
     void LanczosDos(std::size_t idx, std::size_t m, double*) override { log("LanczosDos %zu %zu", idx, m); }
     void Swap(std::size_t i, std::size_t j) override { log("Swap %zu %zu", i, j); }
-    void Lock(std::size_t k) override { log("Lock %zu", k); }
+    void Lock(std::size_t k) override { log("Lock %zu", k); locked_ += k; }
     bool checkSymmetryEasy() override { return !pseudo_; }
     bool isSym() override { return !pseudo_; }
     bool checkPseudoHermicityEasy() override { return pseudo_; }
     bool isPseudoHerm() override { return pseudo_; }
     void symOrHermMatrix(char) override {}
-    void Start() override { log("Start"); }
+    void Start() override { log("Start"); locked_ = 0; it_ = 0; }
     void End() override { log("End"); }
     void initVecs(bool r) override { log("initVecs %d", (int)r); }
     std::size_t GetN() const override { return N_; }
@@ -327,6 +345,47 @@ void run_all()
         std::printf("O ret 1 %zu\n", ret);
         k.flush();
     }
+    // ---- whole solves on scripted Ritz values / residuals: solve :1376-1788 and solve_pseudo :1834-2220 ---------------------
+    // (control flow only: bounds, degree optimisation, condition estimates, locking, K-conjugation calls, final ordering)
+    for (int pseudo = 0; pseudo < 2; ++pseudo)
+        for (int sc = 0; sc < 3; ++sc) {
+            Lcg g(900 + 10 * pseudo + sc);
+            const std::size_t nev = 12 + 4 * sc, nex = 5 + sc, nevex = nev + nex;
+            const int N = 2000, numvec = 4, m = (int)std::min<std::size_t>(nevex, 24) / 2 * 2;
+            K k((std::size_t)N, nev, nex, pseudo != 0);
+            if (sc == 1) k.GetConfig().SetOpt(false);
+            if (sc == 2) { k.GetConfig().SetDeg(12); k.GetConfig().SetMaxIter(9); }
+            k.theta.resize((std::size_t)numvec * m); k.tau.resize((std::size_t)numvec * m); k.ritzV.resize((std::size_t)m * m);
+            for (int r = 0; r < numvec; ++r) {
+                std::vector<double> th(m), w(m);
+                double ws = 0;
+                if (pseudo) for (int i = 0; i < m / 2; ++i) { const double a = 1.5 + 8.5 * g.u(); th[i] = -a; th[m - 1 - i] = a; }
+                else { for (int i = 0; i < m; ++i) th[i] = -10.0 + 20.0 * g.u(); if (r == numvec - 1) th[0] = -10.5; }
+                for (int i = 0; i < m; ++i) { w[i] = 0.05 + g.u(); ws += w[i]; }
+                std::sort(th.begin(), th.end());
+                for (int i = 0; i < m; ++i) { k.theta[(std::size_t)r * m + i] = th[i]; k.tau[(std::size_t)r * m + i] = w[i] / ws; }
+            }
+            for (auto& x : k.ritzV) x = g.u() - 0.5;
+            k.upperb_script = 11.0;
+            // wanted eigenvalues well outside the filter's damped interval; residuals shrink at 0.02 .. 0.2 per iteration
+            k.eig.resize(nevex); k.r0.resize(nevex); k.decay.resize(nevex);
+            for (std::size_t i = 0; i < nevex; ++i) k.eig[i] = pseudo ? 0.3 + 0.6 * g.u() : -30.0 + 10.0 * g.u();
+            std::sort(k.eig.begin(), k.eig.end());
+            for (std::size_t i = 0; i < nevex; ++i) { k.r0[i] = 0.05 + 0.3 * g.u(); k.decay[i] = 0.02 + 0.18 * g.u(); }
+            if (sc == 2) for (std::size_t i = 0; i < nevex; i += 4) k.decay[i] = 0.9;        // stragglers: maxIter / early-lock paths
+            std::printf("S %s %d\n", pseudo ? "solve_pseudo" : "solve", sc);
+            put("I", "theta", k.theta); put("I", "tau", k.tau); put("I", "ritzV", k.ritzV);
+            put("I", "eig", k.eig); put("I", "r0", k.r0); put("I", "decay", k.decay);
+            std::printf("I params 8 %d %d %d %zu %zu %d %zu %zu\n", N, numvec, m, nev, nex, (int)k.GetConfig().DoOptimization(),
+                        (std::size_t)k.GetConfig().GetDeg(), (std::size_t)k.GetConfig().GetMaxIter());
+            k.GetConfig().SetNumLanczos((std::size_t)numvec);
+            k.GetConfig().SetLanczosIter((std::size_t)m);
+            if (pseudo) Calls::solve_pseudo(&k); else Calls::solve(&k);
+            std::vector<double> rv(k.GetRitzv(), k.GetRitzv() + nevex), rs(k.GetResid(), k.GetResid() + nevex);
+            put("O", "ritzv", rv); put("O", "resid", rs);
+            std::printf("O locked 1 %zu\n", k.locked_);
+            k.flush();
+        }
 }
 
 } // namespace scen

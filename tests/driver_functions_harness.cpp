@@ -52,6 +52,8 @@ struct OwnCalls {
     {
         return A::lanczos_for_H2(k, N, nv, m, nevex, ub, ritzv);
     }
+    static void solve(Kernel* k) { A::solve(k); }
+    static void solve_pseudo(Kernel* k) { A::solve_pseudo(k); }
 };
 
 int main()

@@ -55,6 +55,8 @@ struct RefCalls {
     {
         return A::lanczos_for_H2(k, N, nv, m, nevex, ub, true, ritzv);
     }
+    static void solve(Kernel* k) { A::solve(k); }
+    static void solve_pseudo(Kernel* k) { A::solve_pseudo(k); }
 };
 
 int main()

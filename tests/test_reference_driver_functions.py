@@ -36,7 +36,7 @@ def test_own_driver_routines_print_the_reference_routines_output(tmp_path):
                    check=True, cwd=ROOT)
     got = subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=300).stdout.splitlines()
     want = _golden_text()
-    assert len(want) > 700 and sum(l.startswith("S ") for l in want) == 33
+    assert len(want) > 3000 and sum(l.startswith("S ") for l in want) == 39
     assert got == want
 
 
@@ -70,12 +70,36 @@ class _Cfg:
 
 
 class _ScriptKernel:
-    """logs the calls in the format of the C++ ScriptKernel; Lanczos returns the scripted Ritz data"""
+    """logs the calls in the format of the C++ ScriptKernel; Lanczos returns the scripted Ritz data; in the whole-solve
+    scenarios RR / Resd hand out the scripted Ritz values and residuals"""
     dt = np.float64
 
     def __init__(self, pseudo, nev=0, nex=0):
         self.pseudo, self.calls, self.config = pseudo, [], _Cfg(nev, nex)
         self.script = None
+        self.eig = None
+        self.locked, self.it = 0, 0
+
+    # whole-solve surface
+    def Start(self): self.calls.append("Start"); self.locked, self.it = 0, 0
+    def End(self): self.calls.append("End")
+    def initVecs(self, r): self.calls.append("initVecs %d" % int(r))
+    def QR(self, f, c): self.calls.append("QR %d %.17g" % (f, c))
+    def ApplyKconjugate(self, b): self.calls.append("ApplyKconjugate %d" % b)
+    def Lock(self, k): self.calls.append("Lock %d" % k); self.locked += k
+
+    def RR(self, ritzv, b):
+        self.calls.append("RR %d" % b)
+        ritzv[:b] = self.eig[self.locked:self.locked + b] * (1.0 + 1e-3 / (self.it + 1))
+        if self.pseudo:
+            ritzv[b:2 * b] = -ritzv[:b]
+        self.it += 1
+
+    def Resd(self, ritzv, resid, f):
+        self.calls.append("Resd %d" % f)
+        sub = self.nevex - self.locked
+        L = self.locked
+        resid[:sub] = self.r0[L:L + sub] * np.power(self.decay[L:L + sub], float(self.it))
 
     def isSym(self): return not self.pseudo
     def isPseudoHerm(self): return self.pseudo
@@ -178,6 +202,22 @@ def test_oracle_routines_reproduce_the_reference_routines(sc):
         ub, idx = O.lanczos_for_H2(k, N, nv, m, nevex, ritzv)
         _close([ub], want["upperb"], "upperb"); _close(ritzv[:nevex], want["ritzv"], "ritzv")
         assert idx == int(want["ret"][0])
+    elif name in ("solve", "solve_pseudo"):
+        N, nv, m, nev, nex, opt, deg, max_iter = (int(x) for x in p)
+        pseudo = name == "solve_pseudo"
+        k = _ScriptKernel(pseudo, nev, nex)
+        k.config = O.Config(N, nev, nex)
+        k.config.opt, k.config.deg, k.config.max_iter = bool(opt), deg, max_iter
+        k.config.num_lanczos, k.config.lanczos_iter = nv, m
+        k.config.cluster_aware, k.config.upperb_scale = True, 1.0
+        k.nevex = nev + nex
+        k.ritzv, k.resid = np.zeros(2 * k.nevex), np.zeros(2 * k.nevex)
+        k.script = {"ub": 11.0, "theta": I["theta"], "tau": I["tau"], "ritzV": I["ritzV"]}
+        k.eig, k.r0, k.decay = I["eig"], I["r0"], I["decay"]
+        (O.solve_pseudo if pseudo else O.solve)(k)
+        _close(k.ritzv[:k.nevex], want["ritzv"], "ritzv"); _close(k.resid[:k.nevex], want["resid"], "resid")
+        assert k.locked == int(want["locked"][0])
+        sc = dict(sc, C=[c for c in sc["C"] if not c.startswith("FilterPhase")])
     else:
         raise AssertionError("unknown scenario " + name)
     _same_calls(k.calls, sc["C"])
