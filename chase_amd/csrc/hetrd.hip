@@ -7,8 +7,8 @@
 // strong-scaling bottleneck (n = 2560: 1.3 s on 16 host threads per iteration vs 0.18 s of filter GEMM per step).
 // Default: BLOCKED reduction (LAPACK xLATRD / xHETRD 'L' structure, panels of 32 columns, ltrd_* kernels below): one pass
 // over the trailing block and three launches per column, the rank-64 trailing update through the MFMA GEMM once per panel.
-// n = 2560 complex: tridiagonalisation 104 -> 81 ms (profiles/r02_heevd.txt); what is left is the chain of three dependent
-// launches per column (three global reductions: |x|^2, A v, w^H v) at ~10 us each.
+// n = 2560 complex: tridiagonalisation 104 -> 63 ms (profiles/r02_heevd.txt); what is left is the chain of three dependent
+// launches per column (three global reductions: |x|^2, A v, w^H v) at ~8 us each.
 // CHASE_HIP_TRD_UNBLOCKED=1 selects the round-1 algorithm = LAPACK xHETD2 ('L'): per column four launches,
 //   larfg      reflector of column k (single workgroup, wave-shuffle norm)
 //   gemv       partial products of the trailing block with v over 32-column chunks   (HBM-bound, one pass over A22)
@@ -204,6 +204,8 @@ __global__ __launch_bounds__(256) void trd_her2_kernel(double* __restrict__ A, l
 //   w        p = sum(part) - V (W^H v) - W (V^H v), w = tau p, partial w^H v; reflector into A's column
 // X = [V | W] is the panel buffer (n rows, global row index, zero above the reflector heads).
 constexpr int LNB = 32;
+constexpr int LTCW = 128; // largest column chunk of the blocked reduction's GEMV (the host picks 64 or 128: fewer partials to re-add
+                          // for large trailing blocks, enough workgroups for small ones)
 
 template <bool CPLX>
 __global__ __launch_bounds__(256) void ltrd_colupd_kernel(double* __restrict__ A, long lda, int n, int k, int jj,
@@ -280,10 +282,10 @@ __global__ __launch_bounds__(256) void ltrd_gemv_kernel(const double* __restrict
                                                         double* __restrict__ X, const double* __restrict__ npart, int nnp,
                                                         double* __restrict__ part, double* __restrict__ scal,
                                                         double* __restrict__ tau, double* __restrict__ e, int nch,
-                                                        double* __restrict__ coef)
+                                                        double* __restrict__ coef, int tcw)
 {
     constexpr int E = CPLX ? 2 : 1;
-    __shared__ double vs[TCW * 2];
+    __shared__ double vs[LTCW * 2];
     __shared__ double sm[4];
     const int m = n - k - 1;
     double beta, tr, ti, sr, si;
@@ -310,8 +312,8 @@ __global__ __launch_bounds__(256) void ltrd_gemv_kernel(const double* __restrict
         if (threadIdx.x == 0) { coef[2 * b] = ar_; coef[2 * b + 1] = ai_; }
         return;
     }
-    const int j0 = blockIdx.y * TCW;
-    const int jn = min(TCW, m - j0);
+    const int j0 = blockIdx.y * tcw;
+    const int jn = min(tcw, m - j0);
     if ((int)threadIdx.x < jn) { double vr, vi; vof(j0 + threadIdx.x, vr, vi); vs[2 * threadIdx.x] = vr; vs[2 * threadIdx.x + 1] = vi; }
     __syncthreads();
     const int i = blockIdx.x * TRB + threadIdx.x;
@@ -502,15 +504,15 @@ extern "C" int chase_hip_heevd_gpu(chase_hip_ctx* c, int cplx_, int n, void* A_,
                 int ndots_prev = 0;
                 for (int jj = 0; jj < jb; ++jj) {
                     const int k = p0 + jj, m = n - k - 1;
-                    const int nrk = (n - k + TRB - 1) / TRB, nrb = (m + TRB - 1) / TRB, nch = (m + TCW - 1) / TCW;
+                    const int nrk = (n - k + TRB - 1) / TRB, nrb = (m + TRB - 1) / TRB, tcw = (m >= 1792) ? LTCW : LTCW / 2, nch = (m + tcw - 1) / tcw;
                     const int nex = (2 * jj + nrb - 1) / nrb;             // extra grid rows: the 2 jj coefficient workgroups
                     if (cplx) {
                         HK(hipLaunchKernelGGL(ltrd_colupd_kernel<true>, dim3(nrk), dim3(256), 0, st, A, lda, n, k, jj, Xp, tau, dots, ndots_prev, npart, dd));
-                        HK(hipLaunchKernelGGL(ltrd_gemv_kernel<true>, dim3(nrb, nch + nex), dim3(256), 0, st, A, lda, n, k, jj, Xp, npart, nrk, part, scal, tau, de, nch, coef));
+                        HK(hipLaunchKernelGGL(ltrd_gemv_kernel<true>, dim3(nrb, nch + nex), dim3(256), 0, st, A, lda, n, k, jj, Xp, npart, nrk, part, scal, tau, de, nch, coef, tcw));
                         HK(hipLaunchKernelGGL(ltrd_w_kernel<true>, dim3(nrb), dim3(256), 0, st, A, lda, n, k, jj, Xp, part, nch, coef, scal, dots));
                     } else {
                         HK(hipLaunchKernelGGL(ltrd_colupd_kernel<false>, dim3(nrk), dim3(256), 0, st, A, lda, n, k, jj, Xp, tau, dots, ndots_prev, npart, dd));
-                        HK(hipLaunchKernelGGL(ltrd_gemv_kernel<false>, dim3(nrb, nch + nex), dim3(256), 0, st, A, lda, n, k, jj, Xp, npart, nrk, part, scal, tau, de, nch, coef));
+                        HK(hipLaunchKernelGGL(ltrd_gemv_kernel<false>, dim3(nrb, nch + nex), dim3(256), 0, st, A, lda, n, k, jj, Xp, npart, nrk, part, scal, tau, de, nch, coef, tcw));
                         HK(hipLaunchKernelGGL(ltrd_w_kernel<false>, dim3(nrb), dim3(256), 0, st, A, lda, n, k, jj, Xp, part, nch, coef, scal, dots));
                     }
                     ndots_prev = nrb;
