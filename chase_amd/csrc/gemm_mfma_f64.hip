@@ -856,9 +856,9 @@ static int uniform_tile_cols(int m, int n, int k)
 // gain from skipped MFMAs when mixed).  The ragged column therefore gets its own launch, K-split over the whole chip,
 // where every workgroup skips the same 16-column groups.
 template <bool CPLX, bool OPA_C, int TAG>
-static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha, const double* A, long lda,
-                       const double* B, long ldb, const double* beta, double* C, long ldc,
-                       double* ws, size_t ws_bytes, int num_cu, bool allow3m, const LaunchInfo& li)
+static int launch_gemm_cols(hipStream_t st, int m, int n, int k, const double* alpha, const double* A, long lda,
+                            const double* B, long ldb, const double* beta, double* C, long ldc,
+                            double* ws, size_t ws_bytes, int num_cu, bool allow3m, const LaunchInfo& li)
 {
     using C_ = Cfg<CPLX, OPA_C>;
     constexpr int EPT = C_::EPT;
@@ -875,6 +875,48 @@ static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha,
                                                   C + (long)n1 * ldc * EPT, ldc, ws, ws_bytes, num_cu, allow3m, li);
     }
     return launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, allow3m, li);
+}
+
+// The three-multiplication kernel has no guarded path: it needs whole 128-row tiles and whole 8-deep K tiles.  A filter
+// product of ARBITRARY size (N = 1001, a local block of 8193 rows ...) is therefore cut into the part that qualifies,
+//   C[0:m1, :] = alpha op(A)[0:m1, 0:k1] B[0:k1, :] + beta C[0:m1, :]        m1 = m - m mod 128, k1 = k - k mod 8   (3M)
+// plus two thin four-multiplication products for the rims,
+//   C[0:m1, :] += alpha op(A)[0:m1, k1:k] B[k1:k, :]                          (< 8 columns of op(A))
+//   C[m1:m, :]  = alpha op(A)[m1:m, 0:k]  B + beta C[m1:m, :]                 (< 128 rows)
+// instead of running the whole product on four multiplications (25 % more MFMA work) because of a ragged rim.
+template <bool CPLX, bool OPA_C>
+static bool split3m_applies(int m, int n, int k, bool allow3m)
+{
+    using C_ = Cfg<CPLX, OPA_C>;
+    if (!CPLX || !allow3m || gemm3m_enabled() == 0) return false;
+    if (m % C_::BM == 0 && k % C_::BK == 0) return false;              // qualifies as it stands
+    return m >= 8 * C_::BM && k >= 64 * C_::BK && n >= 16;             // the rims must be thin next to the bulk
+}
+
+template <bool CPLX, bool OPA_C, int TAG>
+static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha, const double* A, long lda,
+                       const double* B, long ldb, const double* beta, double* C, long ldc,
+                       double* ws, size_t ws_bytes, int num_cu, bool allow3m, const LaunchInfo& li)
+{
+    using C_ = Cfg<CPLX, OPA_C>;
+    constexpr int EPT = C_::EPT;
+    if (!split3m_applies<CPLX, OPA_C>(m, n, k, allow3m))
+        return launch_gemm_cols<CPLX, OPA_C, TAG>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, allow3m, li);
+    const int m1 = m - m % C_::BM, k1 = k - k % C_::BK;
+    // element (i, kk) of op(A): op = N: A[i + kk lda];  op = C: conj(A[kk + i lda])
+    auto Aoff = [&](int i, int kk) { return A + (OPA_C ? ((long)i * lda + kk) : ((long)kk * lda + i)) * EPT; };
+    const double one[2] = {1.0, 0.0};
+    int rc = launch_gemm_cols<CPLX, OPA_C, TAG>(st, m1, n, k1, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, true, li);
+    if (rc) return rc;
+    if (k1 < k) {
+        rc = launch_gemm_cols<CPLX, OPA_C, TAG>(st, m1, n, k - k1, alpha, Aoff(0, k1), lda, B + (long)k1 * EPT, ldb, one, C, ldc,
+                                                ws, ws_bytes, num_cu, false, li);
+        if (rc) return rc;
+    }
+    if (m1 < m)
+        rc = launch_gemm_cols<CPLX, OPA_C, TAG>(st, m - m1, n, k, alpha, Aoff(m1, 0), lda, B, ldb, beta, C + (long)m1 * EPT, ldc,
+                                                ws, ws_bytes, num_cu, false, li);
+    return rc;
 }
 
 // bytes of split-K workspace this product can use (0: none): the slabs of the tail tiles at the split that minimises the
@@ -914,7 +956,17 @@ size_t gemm_f64_ws_need(bool cplx, char opA, int m, int n, int k, int num_cu)
 {
     const bool opc = (opA == 'C' || opA == 'c' || opA == 'T' || opA == 't');
     if (!cplx) return opc ? ws_need<false, true>(m, n, k, num_cu) : ws_need<false, false>(m, n, k, num_cu);
-    return opc ? ws_need<true, true>(m, n, k, num_cu) : ws_need<true, false>(m, n, k, num_cu);
+    auto need = [&](int mm, int kk) { return opc ? ws_need<true, true>(mm, n, kk, num_cu) : ws_need<true, false>(mm, n, kk, num_cu); };
+    size_t r = need(m, k);
+    // a filter product with ragged rims may be cut into a 3M bulk and two thin 4M rims (launch_gemm): cover those shapes too
+    const bool split = opc ? split3m_applies<true, true>(m, n, k, true) : split3m_applies<true, false>(m, n, k, true);
+    if (split) {
+        const int m1 = m - m % 128, k1 = k - k % 8;
+        r = std::max(r, need(m1, k1));
+        if (k1 < k) r = std::max(r, need(m1, k - k1));
+        if (m1 < m) r = std::max(r, need(m - m1, k));
+    }
+    return r;
 }
 
 int gemm_f64(hipStream_t st, bool cplx, char opA, int m, int n, int k, const double* alpha, const double* A, long lda,

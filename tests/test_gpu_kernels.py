@@ -463,3 +463,35 @@ def test_filter_gemm_is_bitwise_reproducible(ctx):
             assert np.array_equal(outs[0][:, ncols:], W[:, ncols:])
     finally:
         lib.chase_hip_ctx_set_phase(ctx.h, 0)
+
+
+@pytest.mark.parametrize("op", ["N", "C"])
+@pytest.mark.parametrize("m,k,n", [(1153, 1001, 96), (1280, 1003, 133), (1100, 1024, 64)])
+def test_filter_gemm_of_arbitrary_size_uses_3m_for_the_bulk(ctx, op, m, k, n):
+    """A filter product whose sizes are not multiples of the 128-row / 8-deep tiles: the launcher cuts it into a
+    three-multiplication bulk and thin four-multiplication rims (instead of running everything on four multiplications).
+    Result against numpy, untouched surroundings, and the books: executed flops strictly between 3/4 and all of the model."""
+    from chase_amd.capi import lib, gemm_counters
+    rng = np.random.default_rng(m + k + n)
+    A = rnd(rng, (m, k) if op == "N" else (k, m), True)
+    B, Cm = rnd(rng, (k, n + 3), True), rnd(rng, (m + 5, n + 3), True)
+    opA = A if op == "N" else A.conj().T
+    alpha, beta = 0.7 - 0.2j, -0.4 + 0.1j
+    dA, dB, dC = ctx.array(A), ctx.array(B), ctx.array(Cm)
+    lib.chase_hip_ctx_set_phase(ctx.h, 1)
+    try:
+        m0, e0, _ = gemm_counters(ctx, 1)
+        ctx.gemm(op, m, n, k, alpha, dA.ptr, dA.ld, dB.ptr, dB.ld, beta, dC.ptr, dC.ld, True)
+        got = dC.download()
+        m1, e1, _ = gemm_counters(ctx, 1)
+    finally:
+        lib.chase_hip_ctx_set_phase(ctx.h, 0)
+    ref = Cm.copy()
+    ref[:m, :n] = alpha * (opA @ B[:, :n]) + beta * Cm[:m, :n]
+    scale = abs(alpha) * (np.abs(opA) @ np.abs(B[:, :n])) + abs(beta) * np.abs(Cm[:m, :n])
+    assert np.max(np.abs(got[:m, :n] - ref[:m, :n]) / scale) < 8 * GEMM_TOL
+    assert np.array_equal(got[m:, :], Cm[m:, :]) and np.array_equal(got[:, n:], Cm[:, n:])
+    ratio = (e1 - e0) / (m1 - m0)
+    assert m1 - m0 == 2.0 * 4 * m * n * k and 0.75 < ratio < 0.80, ratio
+    for d in (dA, dB, dC):
+        d.free()
