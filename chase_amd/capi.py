@@ -7,7 +7,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libchase_hip.so")
+# CHASE_HIP_LIB: another build of the same library (kernel-development variants, scripts/dev_build_variant.sh)
+LIB_PATH = os.environ.get("CHASE_HIP_LIB") or os.path.join(_HERE, "lib", "libchase_hip.so")
 
 
 class ChaseHipError(RuntimeError):

@@ -3,7 +3,9 @@
 // kept between init / solve / finalize; zchase_ dispatches to the pseudo-Hermitian solver when that is the one that was
 // initialised (chase_c_interface.cpp:2204-2220); the *_internal_ inits own the vector / Ritz-value storage and
 // ?chase_get_eigenpairs_ copies the first nev eigenvectors and Ritz values out (chase_c_interface.cpp:2329-2400).
+#include <dlfcn.h>
 #include <complex>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -133,4 +135,62 @@ void zchase_finalize_(int* flag)
     *flag = 1;
 }
 void chase_enable_sym_check_(int* flag) { if (flag) g_sym_check = *flag != 0; }
+
+/* ---- unified configuration setters and build queries (interface/chase_c_interface.h:207-238,
+ * interface/chase_c_interface.cpp:3795-4260): they act on whichever solver instance is live - sequential or distributed -
+ * and return silently when none is.  tol / deg / opt / approx / cholqr are also arguments of ?chase_ / p?chase_, which set
+ * them again at every solve (chase_c_interface.cpp:444-466,1873-1886); the others persist across solves. */
+chase_hip_solver* chase_hip_cshim_dist_solver(int cplx);
+chase_hip_solver* chase_hip_cshim_seq_solver(int kind) { return kind == 0 ? g_d.s : kind == 1 ? g_z.s : kind == 2 ? g_zp.s : nullptr; }
+static void set_all(const char* key, double v)
+{
+    chase_hip_solver* live[5] = {g_d.s, g_z.s, g_zp.s, chase_hip_cshim_dist_solver(0), chase_hip_cshim_dist_solver(1)};
+    for (chase_hip_solver* s : live)
+        if (s) chase_hip_solver_set(s, key, v);
+}
+void chase_set_tol_(double* v) { if (v) set_all("tol", *v); }
+void chase_set_deg_(int* v) { if (v) set_all("deg", *v); }
+void chase_set_max_deg_(int* v) { if (v) set_all("maxdeg", *v); }
+void chase_set_deg_extra_(int* v) { if (v) set_all("degextra", *v); }
+void chase_set_max_iter_(int* v) { if (v) set_all("maxiter", *v); }
+void chase_set_lanczos_iter_(int* v) { if (v) set_all("lanczositer", *v); }
+void chase_set_num_lanczos_(int* v) { if (v) set_all("numlanczos", *v); }
+void chase_set_approx_(int* v) { if (v) set_all("approx", *v != 0); }
+void chase_set_opt_(int* v) { if (v) set_all("opt", *v != 0); }
+void chase_set_cholqr_(int* v) { if (v) set_all("cholqr", *v != 0); }
+void chase_set_decaying_rate_(float* v) { if (v) set_all("decayingrate", *v); }
+void chase_set_cluster_aware_degrees_(int* v) { if (v) set_all("clusteraware", *v != 0); }
+void chase_set_upperb_scale_rate_(float* v) { if (v) set_all("upperbscale", *v); }
+
+void chase_get_version_(char* version, int* len)
+{
+    if (!version || !len || *len <= 0) return;
+    const char* ver = chase_hip_version();
+    int n = 0;
+    while (ver[n] != '\0' && n < *len - 1) { version[n] = ver[n]; ++n; }
+    version[n] = '\0';
+    *len = n;
+}
+void chase_has_cuda_(int* flag) { if (flag) *flag = 0; }          /* HIP on gfx950, no CUDA anywhere */
+void chase_has_nccl_(int* flag) { if (flag) *flag = 1; }          /* the NCCL API, served by RCCL over xGMI */
+void chase_has_scalapack_(int* flag) { if (flag) *flag = 0; }     /* own distributed Householder QR instead */
+void chase_has_mpi_(int* flag)                                     /* 1 when the MPI front end (libchase_hip_mpi.so) is loaded */
+{
+    if (flag) *flag = dlsym(RTLD_DEFAULT, "pzchase_init_blockcyclic_") != nullptr ? 1 : 0;
+}
+void chase_print_config_()
+{
+    int mpi = 0;
+    chase_has_mpi_(&mpi);
+    std::printf("========================================\nChASE MI355X backend configuration\n========================================\n"
+                "Version: %s\n  HIP / gfx950 kernels:    ENABLED\n  CUDA:                    DISABLED\n"
+                "  RCCL (NCCL API):         ENABLED\n  MPI front end:           %s\n  ScaLAPACK:               DISABLED\n"
+                "  host LAPACK provider:    %s\n", chase_hip_version(), mpi ? "LOADED" : "not loaded", chase_hip_lapack_provider());
+    std::fflush(stdout);
+}
+/* aliases without the leading 'p' (interface/chase_c_interface.h:197-205): forward to p?chase_readHam_ */
+void pdchase_readHam_(const char* filename);
+void pzchase_readHam_(const char* filename);
+void dchase_readHam_(const char* filename) { pdchase_readHam_(filename); }
+void zchase_readHam_(const char* filename) { pzchase_readHam_(filename); }
 }

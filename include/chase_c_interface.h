@@ -43,6 +43,29 @@ void zchase_pseudo_(int* deg, double* tol, char* mode, char* opt, char* qr);
 void dchase_get_eigenpairs_(double* LEigsV, int* ld, double* ritzv);
 void zchase_get_eigenpairs_(void* LEigsV, int* ld, double* ritzv);
 void chase_enable_sym_check_(int* flag);     /* interface/chase_c_interface.cpp:4055: flag kept for callers that set it */
+/* unified configuration setters and build queries (interface/chase_c_interface.h:207-238): act on the live solver instance
+ * (sequential or distributed), silent when none is initialised */
+void chase_set_tol_(double* tol);
+void chase_set_deg_(int* deg);
+void chase_set_max_deg_(int* max_deg);
+void chase_set_deg_extra_(int* deg_extra);
+void chase_set_max_iter_(int* max_iter);
+void chase_set_lanczos_iter_(int* lanczos_iter);
+void chase_set_num_lanczos_(int* num_lanczos);
+void chase_set_approx_(int* flag);
+void chase_set_opt_(int* flag);
+void chase_set_cholqr_(int* flag);
+void chase_set_decaying_rate_(float* decaying_rate);
+void chase_set_cluster_aware_degrees_(int* flag);
+void chase_set_upperb_scale_rate_(float* upperb_scale_rate);
+void chase_get_version_(char* version, int* len);
+void chase_has_cuda_(int* flag);          /* 0 */
+void chase_has_nccl_(int* flag);          /* 1: the NCCL API is served by RCCL */
+void chase_has_scalapack_(int* flag);     /* 0 */
+void chase_has_mpi_(int* flag);           /* 1 when libchase_hip_mpi.so is loaded in the process */
+void chase_print_config_(void);
+void dchase_readHam_(const char* filename);  /* aliases of p?chase_readHam_ */
+void zchase_readHam_(const char* filename);
 
 /* ---- distributed (one process per GPU) ---- */
 struct chase_hip_grid;
@@ -50,6 +73,7 @@ struct chase_hip_ctx;
 struct chase_hip_solver;
 int chase_hip_cshim_use_ctx(struct chase_hip_ctx* ctx, int own); /* context of the NEXT _hip_ init; own: finalize destroys grid + ctx */
 struct chase_hip_solver* chase_hip_cshim_dist_solver(int cplx); /* the live distributed solver (chase_hip_solver.h), or NULL */
+struct chase_hip_solver* chase_hip_cshim_seq_solver(int kind); /* live sequential solver: 0 real, 1 complex, 2 complex pseudo-Hermitian */
 void pdchase_init_hip_(int* N, int* nev, int* nex, int* m, int* n, double* H, int* ldh, double* V, double* ritzv,
                        struct chase_hip_grid* grid, int* init);
 void pdchase_init_internal_hip_(int* N, int* nev, int* nex, int* m, int* n, double* H, int* ldh,

@@ -50,8 +50,9 @@ int chase_hip_psolver_upload_v(chase_hip_solver* s, const void* host, size_t ldv
 int chase_hip_psolver_download_v(chase_hip_solver* s, void* host, size_t ldv);
 int chase_hip_psolver_set_pipeline(chase_hip_solver* s, int on); /* 0: no compute/communication overlap (debug) */
 int chase_hip_solver_destroy(chase_hip_solver* s);
-/* keys: tol deg maxdeg degextra maxiter lanczositer numlanczos opt approx cholqr decayingrate
- * (ChaseConfig setters, algorithm/configuration.hpp:197-462); get additionally: locked qr_variant filter_ms */
+/* keys: tol deg maxdeg degextra maxiter lanczositer numlanczos opt approx cholqr decayingrate clusteraware upperbscale
+ * (ChaseConfig setters, algorithm/configuration.hpp:197-462); get additionally: locked qr_variant filter_ms hemm_calls
+ * hemm_reused_vecs, and iterations / filtered_vecs of the last solve */
 int chase_hip_solver_set(chase_hip_solver* s, const char* key, double value);
 int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* value);
 int chase_hip_solver_solve(chase_hip_solver* s, int record_trace);

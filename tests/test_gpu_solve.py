@@ -300,6 +300,51 @@ def test_c_interface_internal_storage_and_get_eigenpairs(ctx):
     assert flag.value == 1
 
 
+def test_c_interface_unified_setters_and_queries(ctx):
+    """chase_set_*_ / chase_get_version_ / chase_has_*_ (interface/chase_c_interface.h:207-238): the setters reach the live
+    solver's configuration (silently nothing without one), max_iter caps the next solve, the per-solve arguments win over
+    chase_set_tol_/deg_ as in the reference (chase_c_interface.cpp:444-466)."""
+    import ctypes as C
+    from chase_amd.capi import lib
+    ci = lambda v: C.byref(C.c_int(v))
+    lib.chase_set_max_iter_(ci(3))                                  # no live solver: returns
+    buf = C.create_string_buffer(64); n = C.c_int(64)
+    lib.chase_get_version_(buf, C.byref(n))
+    assert n.value == len(buf.value) > 0
+    flags = {}
+    for q in ("cuda", "nccl", "scalapack", "mpi"):
+        f = C.c_int(-1); getattr(lib, f"chase_has_{q}_")(C.byref(f)); flags[q] = f.value
+    assert flags["cuda"] == 0 and flags["nccl"] == 1 and flags["scalapack"] == 0 and flags["mpi"] in (0, 1)
+    N, nev, nex = 256, 24, 16
+    H = O.clement(N, False)
+    V = np.zeros((N, nev + nex), order="F"); lam = np.zeros(nev + nex)
+    init = C.c_int(0)
+    lib.dchase_init_(ci(N), ci(nev), ci(nex), C.c_void_p(H.ctypes.data), ci(N), C.c_void_p(V.ctypes.data),
+                     C.c_void_p(lam.ctypes.data), C.byref(init))
+    lib.chase_hip_cshim_seq_solver.restype = C.c_void_p
+    sp = C.c_void_p(lib.chase_hip_cshim_seq_solver(0))
+    assert sp.value
+    def get(key):
+        out = C.c_double(0)
+        assert lib.chase_hip_solver_get(sp, key.encode(), C.byref(out)) == 0
+        return out.value
+    lib.chase_set_max_iter_(ci(1)); lib.chase_set_deg_extra_(ci(4)); lib.chase_set_max_deg_(ci(30))
+    lib.chase_set_lanczos_iter_(ci(20)); lib.chase_set_num_lanczos_(ci(3))
+    lib.chase_set_decaying_rate_(C.byref(C.c_float(0.5))); lib.chase_set_upperb_scale_rate_(C.byref(C.c_float(1.5)))
+    lib.chase_set_cluster_aware_degrees_(ci(0)); lib.chase_set_tol_(C.byref(C.c_double(1e-3)))
+    assert (get("maxiter"), get("degextra"), get("maxdeg"), get("lanczositer"), get("numlanczos")) == (1, 4, 30, 20, 3)
+    assert (get("decayingrate"), get("upperbscale"), get("clusteraware"), get("tol")) == (0.5, 1.5, 0, 1e-3)
+    lib.dchase_(ci(10), C.byref(C.c_double(1e-10)), C.c_char_p(b"R"), C.c_char_p(b"S"), C.c_char_p(b"C"))
+    assert get("iterations") == 1 and get("tol") == 1e-10           # capped by max_iter; tol from the solve call
+    lib.chase_set_max_iter_(ci(25)); lib.chase_set_decaying_rate_(C.byref(C.c_float(1.0)))
+    lib.dchase_(ci(10), C.byref(C.c_double(1e-10)), C.c_char_p(b"R"), C.c_char_p(b"S"), C.c_char_p(b"C"))
+    assert np.max(O.residuals(H, lam[:nev].copy(), V[:, :nev])) < RESID_TOL
+    lib.chase_print_config_()
+    flag = C.c_int(0)
+    lib.dchase_finalize_(C.byref(flag))
+    assert flag.value == 1 and not lib.chase_hip_cshim_seq_solver(0)
+
+
 def test_c_interface_pseudo_hermitian(ctx):
     """zchase_init_pseudo_ + zchase_ (dispatches to the pseudo solver, chase_c_interface.cpp:2204-2220) + zchase_pseudo_ +
     zchase_get_eigenpairs_ on the reference's BSE fixture."""
