@@ -312,7 +312,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
         }
     };
 
-    auto mfma_chunk = [&](const Frag& f) __attribute__((always_inline)) {
+    // `hook(slot)` runs after every group of MFMAs (4M: 4 MFMAs, real: TM, 3M: 3; slots 0..2 TN-1 in each case): the
+    // LDS-DMA loops hang the global -> LDS copies of the next tile there, one copy under each group's MFMAs
+    auto no_hook = [](int) __attribute__((always_inline)) {};
+    auto mfma_chunk = [&](const Frag& f, auto&& hook) __attribute__((always_inline)) {
         constexpr bool FULL = !RAGGED;                        // FULL: every 16-column group is live (no per-group branches)
         if constexpr (CPLX && M3) {
             double sa[TM], sb[TN];
@@ -321,14 +324,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
             #pragma unroll
             for (int j = 0; j < TN; ++j) sb[j] = f.b[j].x + f.b[j].y;
             #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                if (FULL || j < jv)
+            for (int j = 0; j < TN; ++j) {
                 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.b[j].x, f.a[i][0], acc[0][j][i], 0, 0, 0);
-                    acc[1][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.b[j].y, f.a[i][1], acc[1][j][i], 0, 0, 0);
-                    acc[2][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(sb[j], sa[i], acc[2][j][i], 0, 0, 0);
+                    if (FULL || j < jv) {
+                        acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.b[j].x, f.a[i][0], acc[0][j][i], 0, 0, 0);
+                        acc[1][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.b[j].y, f.a[i][1], acc[1][j][i], 0, 0, 0);
+                        acc[2][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(sb[j], sa[i], acc[2][j][i], 0, 0, 0);
+                    }
+                    hook(TM * j + i);
                 }
+            }
         } else if constexpr (CPLX) {
             // op=N: (ar + i ai)(br + i bi): re = br ar - bi ai, im = bi ar + br ai
             // op=C: (ar - i ai)(br + i bi): re = br ar + bi ai, im = bi ar - br ai      -> one negated B value per tile
@@ -336,49 +342,59 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
             #pragma unroll
             for (int j = 0; j < TN; ++j) nb[j] = OPA_C ? -f.b[j].x : -f.b[j].y;
             #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j) {
                 if (FULL || j < jv)
                 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.b[j].x, f.a[i][0], acc[0][j][i], 0, 0, 0);
                     acc[1][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.b[j].y, f.a[i][0], acc[1][j][i], 0, 0, 0);
                 }
+                hook(j);
+            }
             #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j) {
                 if (FULL || j < jv)
                 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(OPA_C ? f.b[j].y : nb[j], f.a[i][1], acc[0][j][i], 0, 0, 0);
                     acc[1][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(OPA_C ? nb[j] : f.b[j].x, f.a[i][1], acc[1][j][i], 0, 0, 0);
                 }
+                hook(TN + j);
+            }
         } else {
             #pragma unroll
             for (int s = 0; s < 2; ++s)
                 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j) {
                     if (FULL || j < jv)
                     #pragma unroll
                     for (int i = 0; i < TM; ++i)
                         acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(
                             s == 0 ? f.b[j].x : f.b[j].y, f.a[i][s], acc[0][j][i], 0, 0, 0);
+                    hook(s * TN + j);
+                }
         }
     };
 
     // whole K step from one LDS stage (register-staged fallback path)
-    auto compute = [&](int stage) __attribute__((always_inline)) {
+    auto compute = [&](int stage, auto&& hook) __attribute__((always_inline)) {
         if constexpr (CPLX && !M3) {
             Frag f0, f1;
             read_chunk(stage, 0, f0);
             read_chunk(stage, 1, f1);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk(f0);
-            mfma_chunk(f1);
+            mfma_chunk(f0, hook);
+            mfma_chunk(f1, no_hook);
         } else {                                             // 40 fragment registers per chunk: one chunk at a time
-            #pragma unroll
-            for (int ch = 0; ch < 2; ++ch) {
+            {
                 Frag f;
-                read_chunk(stage, ch, f);
-                mfma_chunk(f);
+                read_chunk(stage, 0, f);
+                mfma_chunk(f, hook);
+            }
+            {
+                Frag f;
+                read_chunk(stage, 1, f);
+                mfma_chunk(f, no_hook);
             }
         }
     };
@@ -468,28 +484,44 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                 asm volatile("" ::: "memory");
                 Frag fA, fB;
                 read_chunk(0, 0, fA);
-                int st = 0;
-                for (int kt = 0; kt < nfull; ++kt) {
+                constexpr std::true_type yes{};
+                constexpr std::false_type no{};
+                // one K step on the tile in stage st (not the last one); `fill`: tile kt+STAGES exists and goes into stage st,
+                // one copy after every fourth MFMA of the second cluster
+                auto kstep = [&](int kt, int st, auto fill_c) __attribute__((always_inline)) {
                     const int stn = (st + 1 == C_::STAGES) ? 0 : st + 1;
                     read_chunk(st, 1, fB);
                     __builtin_amdgcn_sched_barrier(0);
-                    mfma_chunk(fA);
+                    mfma_chunk(fA, no_hook);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (kt + 1 < nfull) {
-                        // my reads of stage st are complete (it is refilled below) and my copies of tile kt+1 have landed;
-                        // a later tile may stay in flight (three stages)
-                        if (C_::STAGES > 2 && kt + 2 < nfull) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
-                        else                                  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();
-                        asm volatile("" ::: "memory");
-                        read_chunk(stn, 0, fA);
-                        if (kt + C_::STAGES < nfull) issue();                 // tile kt+STAGES into stage st
-                    }
+                    // my reads of stage st are complete (it is refilled below) and my copies of tile kt+1 have landed;
+                    // a later tile may stay in flight (three stages)
+                    if (C_::STAGES > 2 && (decltype(fill_c)::value || kt + 2 < nfull))
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
+                    else
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    read_chunk(stn, 0, fA);
                     __builtin_amdgcn_sched_barrier(0);
-                    mfma_chunk(fB);
+                    mfma_chunk(fB, [&](int slot) __attribute__((always_inline)) {
+                        if (decltype(fill_c)::value && slot < NA + NB) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue_one(slot, st);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    });
                     __builtin_amdgcn_sched_barrier(0);
-                    st = stn;
-                }
+                };
+                static_assert(2 * TN >= NA + NB, "one copy per MFMA group of the cluster");
+                int st = 0, kt = 0;
+                for (; kt + C_::STAGES < nfull; ++kt) { kstep(kt, st, yes); st = (st + 1 == C_::STAGES) ? 0 : st + 1; }
+                for (; kt + 1 < nfull; ++kt)          { kstep(kt, st, no);  st = (st + 1 == C_::STAGES) ? 0 : st + 1; }
+                read_chunk(st, 1, fB);                                         // last tile: nothing to publish or prefetch
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_chunk(fA, no_hook);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_chunk(fB, no_hook);
             } else if constexpr (CPLX && M3 && CHASE_M3_PIPELINE) {
                 // 3M software pipeline.  192 accumulator registers leave no room for a second set of fragments, so only
                 // the A fragments (8 registers) are double-buffered; each B fragment is REFILLED IN PLACE with the next
@@ -596,17 +628,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                 issue();
                 if (DEPTH > 1 && nfull > 1) issue();
                 int st_comp = 0;
-                for (int kt = 0; kt < nfull; ++kt) {
+                // the copies of tile kt+DEPTH go out under the first MFMA groups of tile kt's first cluster (one copy per
+                // group), into the stage whose last reader passed the barrier of this step
+                auto kstep = [&](int kt, auto fill_c) __attribute__((always_inline)) {
                     // my own copies of tile kt have landed (with three stages tile kt+1 may stay in flight) ...
                     if (DEPTH > 1 && kt + 1 < nfull) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C_::GLDS_PER_WAVE) : "memory");
                     else                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     // ... and after the barrier everybody's have; everybody has also finished reading the stage refilled next
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
-                    if (kt + DEPTH < nfull) issue();
-                    compute(st_comp);
+                    const int st_fill = (st_comp + DEPTH) % C_::STAGES;
+                    compute(st_comp, [&](int slot) __attribute__((always_inline)) {
+                        if (decltype(fill_c)::value && slot < NA + NB) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue_one(slot, st_fill);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    });
                     st_comp = (st_comp + 1 == C_::STAGES) ? 0 : st_comp + 1;
-                }
+                };
+                static_assert(2 * TN >= NA + NB, "one copy per MFMA group of the cluster");
+                int kt = 0;
+                for (; kt + DEPTH < nfull; ++kt) kstep(kt, std::true_type());
+                for (; kt < nfull; ++kt)         kstep(kt, std::false_type());
             }
             if constexpr (!M3) {
             // a partial last K tile goes through the guarded register path into the stage nobody reads any more
@@ -616,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                 load_tile(kbeg + nfull * BK);
                 store_tile(st);
                 __syncthreads();
-                compute(st);
+                compute(st, no_hook);
             }
             }
             done = true;
@@ -630,7 +674,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
         for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < nkt) load_tile(kbeg + (kt + 1) * BK);
-            compute(cur);
+            compute(cur, no_hook);
             if (kt + 1 < nkt) store_tile(cur ^ 1);
             __syncthreads();
         }
