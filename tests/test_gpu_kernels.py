@@ -214,6 +214,29 @@ def test_potrf_and_trsm(ctx, cplx, n):
 
 
 @pytest.mark.parametrize("cplx", [False, True])
+def test_reference_small_kernel_known_answers(ctx, cplx):
+    """The reference's own known-answer tests of the small helpers on the path, same inputs and expected values:
+    absTrace (tests/linalg/internal/cuda/absTrace.cpp:27-53: 3x3 in ld 4, entries i+1, buffer[5] = -4 -> 16),
+    shiftDiagonal (cuda/shiftDiagonal.cpp:28-62: 4x3, shift -2 -> {-1,2,3,4,5,4,7,8,9,10,9,12}),
+    lacpy full copy (cuda/lacpy.cpp:28-58: 3x3 out of ld 4 into ld 3)."""
+    from chase_amd.capi import lib, check
+    dt = np.complex128 if cplx else np.float64
+    buf = np.arange(1, 13, dtype=dt)
+    b = buf.copy(); b[5] = -4
+    dA = ctx.array(np.asfortranarray(b.reshape((4, 3), order="F")))
+    out = C.c_double(0)
+    check(lib.chase_hip_abs_trace(ctx.h, int(cplx), 3, dA.ptr, 4, C.byref(out)), "abs_trace")
+    assert out.value == 16.0
+    dB = ctx.array(np.asfortranarray(buf.reshape((4, 3), order="F")))
+    check(lib.chase_hip_shift_diag(ctx.h, int(cplx), 3, dB.ptr, 4, -2.0), "shift")
+    assert np.array_equal(dB.download().ravel(order="F"), np.array([-1, 2, 3, 4, 5, 4, 7, 8, 9, 10, 9, 12], dtype=dt))
+    dS = ctx.array(np.asfortranarray(buf.reshape((4, 3), order="F")))
+    dT = ctx.empty((3, 3), dt)
+    check(lib.chase_hip_lacpy(ctx.h, int(cplx), 3, 3, dS.ptr, 4, dT.ptr, 3), "lacpy")
+    assert np.array_equal(dT.download(), buf.reshape((4, 3), order="F")[:3, :])
+
+
+@pytest.mark.parametrize("cplx", [False, True])
 def test_shift_swap_lacpy_resid(ctx, cplx):
     from chase_amd.capi import lib, check
     rng = np.random.default_rng(11)
