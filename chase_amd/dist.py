@@ -285,6 +285,9 @@ class DistSolver:
 
     def Lanczos(self, M, numvec):
         ub = c_double()
+        if numvec == 0:                     # single-vector form: upper bound only (interface.hpp Lanczos(m, upperb))
+            check(lib.chase_hip_op_lanczos(self.h, M, 0, C.byref(ub), None, None, None), "Lanczos")
+            return ub.value
         theta, tau, ritzV = np.zeros(M * numvec), np.zeros(M * numvec), np.zeros(M * M)
         check(lib.chase_hip_op_lanczos(self.h, M, numvec, C.byref(ub), theta.ctypes.data, tau.ctypes.data,
                                        ritzV.ctypes.data), "Lanczos")

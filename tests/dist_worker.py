@@ -153,6 +153,79 @@ def scenario_ops(ctx, grid, rank, world, cplx, mb):
     s.close()
 
 
+def scenario_reference_units(ctx, grid, rank, world, cplx, mb):
+    """The reference's distributed kernel tests (tests/linalg/internal/mpi/{rayleighRitz,residuals,lanczos}.cpp and their
+    nccl/ twins) through the grid Impl: same matrices, the reference's assertions and tolerances."""
+    dt = np.complex128 if cplx else np.float64
+
+    def rand_unitary(N):
+        g = O.StdNormal(1337)
+        d = g.draw(2 * N * N if cplx else N * N)
+        X = (d[0::2] + 1j * d[1::2] if cplx else d).reshape((N, N), order="F")
+        return np.linalg.qr(X)[0]
+
+    def make(H, nev, nex, V):
+        N = H.shape[0]
+        rl, cl = cd.Layout(N, mb, grid.nprow), cd.Layout(N, mb, grid.npcol)
+        rows = rl.globals_of(grid.myrow)
+        dH = ctx.array(cd.local_block_of(np.asfortranarray(H), rl, cl, grid.myrow, grid.mycol))
+        s = cd.DistSolver(ctx, grid, dH, N, nev, nex, cplx, mb, mb)
+        s.Start()
+        if V is None:
+            s.initVecs(True)
+        else:
+            s.upload_local_V(np.asfortranarray(V[rows, :])); s.initVecs(False)
+        return s
+
+    # mpi/rayleighRitz.cpp (cpu/rayleighRitz.cpp:48-118): H = Q diag(0.1 (i+1)) Q^H, N = 50, n = 10, offset 2, 5 columns: 100 eps
+    N, n, offset, sub = 50, 10, 2, 5
+    Q = rand_unitary(N)
+    H = (Q * (0.1 * np.arange(N) + 0.1)[None, :]) @ Q.conj().T
+    H = ((H + H.conj().T) / 2).astype(dt)
+    evals, evecs = np.linalg.eigh(H)
+    s = make(H, n - 2, 2, evecs[:, :n].astype(dt))
+    s.Lock(offset)
+    s.RR(sub, offset)
+    assert np.max(np.abs(s.ritzv[offset:offset + sub] - evals[offset:offset + sub])) <= 100 * EPS
+    s.close()
+    note("reference RR ok")
+    # mpi/residuals.cpp: diagonal H = diag(1..64) with unit vectors: within 10 eps of eps; dense H with LAPACK's eigenpairs,
+    # columns 2..11: within 100 eps
+    N = 64
+    s = make(np.diag(np.arange(1.0, N + 1)).astype(dt), N - 1, 1, np.eye(N, dtype=dt))
+    s.ritzv[:] = np.arange(1.0, N + 1)
+    r = s.Resd(0)
+    assert np.all(np.abs(r - EPS) <= 10 * EPS), r[:4]
+    s.close()
+    Q = rand_unitary(N)
+    H = (Q * (0.1 * np.arange(N) + 0.1)[None, :]) @ Q.conj().T
+    H = ((H + H.conj().T) / 2).astype(dt)
+    evals, evecs = np.linalg.eigh(H)
+    s = make(H, N - 1, 1, evecs.astype(dt))
+    s.ritzv[:] = evals
+    s.Lock(2)
+    r = s.Resd(2)
+    assert np.all(np.abs(r[:10] - EPS) <= 100 * EPS), r[:10]
+    s.close()
+    note("reference residuals ok")
+    # mpi/lanczos.cpp: Clement N = 500 (fixture entries of lanczos.cpp:38-46), M = 10, 4 vectors / 1 vector
+    N, M, numvec = 500, 10, 4
+    H = np.zeros((N, N), dtype=dt)
+    i = np.arange(N - 1)
+    off = np.sqrt(i * (N + 1.0 - i))
+    H[i + 1, i] = off; H[i, i + 1] = off
+    s = make(H, 8, 4, None)
+    ub, theta, tau, _ = s.Lanczos(M, numvec)
+    th = theta.reshape(numvec, M)
+    assert np.all(th[:, 0] > 1.0 - N) and np.all(th[:, M - 1] < N - 1.0)
+    assert N - 1 < ub < 5 * (N - 1)
+    s.initVecs(True)
+    ub1 = s.Lanczos(M, 0)
+    assert N - 1 < ub1 < 5 * (N - 1)
+    s.close()
+    note("reference Lanczos ok")
+
+
 def scenario_solve(ctx, grid, rank, world, N, nev, nex, cplx, mb, deg):
     """Full distributed solve vs the serial oracle (tests/chase_distributed_solve.cpp:38-115,209-284)."""
     H = O.clement(N, cplx)
@@ -510,6 +583,8 @@ def main():
         elif scen == "solve":
             N, nev, nex = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
             scenario_solve(ctx, grid, rank, world, N, nev, nex, sys.argv[6] == "z", int(sys.argv[7]), int(sys.argv[8]))
+        elif scen == "reference_units":
+            scenario_reference_units(ctx, grid, rank, world, sys.argv[3] == "z", int(sys.argv[4]))
         elif scen == "refcounts":
             scenario_reference_run_counts(ctx, grid, rank, world)
         elif scen == "qr_fixtures":

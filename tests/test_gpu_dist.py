@@ -106,6 +106,12 @@ def test_pseudo_solve_real_fixture(nranks, mb):
     run_ranks(nranks, "host", "pseudo_solve_real", mb)
 
 
+@pytest.mark.parametrize("nranks,typ,mb", [(4, "d", 0), (4, "z", 0), (4, "z", 8), (2, "d", 16)])
+def test_reference_distributed_kernel_tests(nranks, typ, mb):
+    """tests/linalg/internal/mpi/{rayleighRitz,residuals,lanczos}.cpp (2 x 2 grid in the reference) through the grid Impl"""
+    run_ranks(nranks, "host", "reference_units", typ, mb)
+
+
 @pytest.mark.parametrize("nranks,typ,mb", [(4, "d", 0), (4, "z", 32), (2, "z", 0)])
 def test_distributed_c_entry_points(nranks, typ, mb):
     """p?chase_init[_blockcyclic]_hip_ / p?chase_ / p?chase_get_eigenpairs_ / p?chase_wrtHam_ / readHam_ / finalize_"""
