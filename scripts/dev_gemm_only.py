@@ -11,6 +11,7 @@ reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 op = sys.argv[5] if len(sys.argv) > 5 else "N"
 pad = int(sys.argv[6]) if len(sys.argv) > 6 else 0          # extra rows in the leading dimensions (set-aliasing probe)
 data = sys.argv[7] if len(sys.argv) > 7 else "normal"       # "clement": the bench's matrix (x 100/N, perturbation 1e-6) as A
+M = int(os.environ.get("DEV_M", "0")) or N               # rows of A and C (op N only): one-round launches for L2 studies
 with Context(0) as ctx:
     dt = np.complex128 if cplx else np.float64
     L = N + pad
@@ -23,10 +24,10 @@ with Context(0) as ctx:
     check(lib.chase_hip_fill_normal(ctx.h, int(cplx), L, n, dB.ptr, L, 0, 0, L, 2), "fill")
     check(lib.chase_hip_fill_normal(ctx.h, int(cplx), L, n, dC.ptr, L, 0, 0, L, 3), "fill")
     lib.chase_hip_ctx_set_phase(ctx.h, 1)
-    ctx.gemm(op, N, n, N, 0.5, dA.ptr, L, dB.ptr, L, 0.25, dC.ptr, L, cplx)
+    ctx.gemm(op, M, n, N, 0.5, dA.ptr, L, dB.ptr, L, 0.25, dC.ptr, L, cplx)
     ctx.timer_start()
     for _ in range(reps):
-        ctx.gemm(op, N, n, N, 0.5, dA.ptr, L, dB.ptr, L, 0.25, dC.ptr, L, cplx)
+        ctx.gemm(op, M, n, N, 0.5, dA.ptr, L, dB.ptr, L, 0.25, dC.ptr, L, cplx)
     ms = ctx.timer_stop() / reps
     if os.environ.get("DEV_PER_LAUNCH"):            # sustained-load drift: time launches one by one
         per = []
@@ -39,4 +40,4 @@ with Context(0) as ctx:
         k = max(len(tf) // 6, 1)
         print("per-launch TFLOP/s, consecutive groups:", " ".join(f"{sum(tf[i:i+k])/len(tf[i:i+k]):.2f}" for i in range(0, len(tf), k)), flush=True)
     F = 4 if cplx else 1
-    print(f"HEMM cplx={cplx} op={op} N={N} n={n} ld={L} tile_group={os.environ.get('CHASE_HIP_TILE_GROUP', 'default')} A={data}: {ms:.3f} ms {2.0*F*N*N*n/(ms*1e-3)/1e12:.2f} TFLOP/s", flush=True)
+    print(f"HEMM cplx={cplx} op={op} M={M} N={N} n={n} ld={L} tile_group={os.environ.get('CHASE_HIP_TILE_GROUP', 'default')} A={data}: {ms:.3f} ms {2.0*F*M*N*n/(ms*1e-3)/1e12:.2f} TFLOP/s", flush=True)
