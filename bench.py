@@ -243,6 +243,9 @@ def roofline_object(model_flops, exec_flops, filt_s, calls, world, note_extra=""
             "executed_over_model": exec_flops / model_flops if model_flops else None,
             "launches": calls, "avg_launch_ms": filt_s * 1e3 / max(calls, 1),
             "flop_per_launch_avg": model_flops / max(calls, 1) / world,
+            # what a register-resident loop of v_mfma_f64_16x16x4_f64 sustains on this part (64.00 cycles per instruction at
+            # 2.39 GHz, scripts/dev_mfma_f64_peak.hip, profiles/r02_mfma_f64_issue.txt): context for `frac`, not its denominator
+            "bare_mfma_loop_tflops": 77.5,
             "launch_unit": "one HEMM call per GPU = whole-tile kernel (+ ragged-column kernel when the width is not a "
                            "multiple of the tile width) + tail reduce; rocprofv3: sum over the TAG=1 kernels",
             "note": "achieved/frac = flops the matrix cores EXECUTE (the complex filter kernel forms each complex product "
