@@ -216,6 +216,7 @@ _sig("chase_hip_set_lapack_lib", c_int, C.c_char_p)
 _sig("chase_hip_lapack_provider", C.c_char_p)
 _sig("chase_hip_set_host_threads", c_int, c_int)
 _sig("chase_hip_ctx_set_phase", c_int, c_void_p, c_int)
+_sig("chase_hip_ctx_set_gemm_min_rounds", c_int, c_void_p, c_int)
 _sig("chase_hip_fill_normal", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_long, c_long, c_long,
      C.c_ulonglong)
 _sig("chase_hip_gen_clement", c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_int, c_long, c_int, c_int, c_int,

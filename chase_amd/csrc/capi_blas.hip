@@ -94,6 +94,13 @@ int chase_hip_ctx_set_phase(chase_hip_ctx* c, int phase)
     return 0;
 }
 
+int chase_hip_ctx_set_gemm_min_rounds(chase_hip_ctx* c, int rounds)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "ctx_set_gemm_min_rounds: NULL context");
+    c->gemm_min_rounds = rounds < 0 ? 0 : (rounds > 16 ? 16 : rounds);
+    return 0;
+}
+
 /* X (m x n local window whose first element is global (grow0, gcol0) of a matrix with gld global rows) ~ N(0,1) */
 int chase_hip_fill_normal(chase_hip_ctx* c, int cplx, int m, int n, void* X, long ldx, long grow0, long gcol0, long gld,
                           unsigned long long seed)

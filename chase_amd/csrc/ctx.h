@@ -17,6 +17,7 @@ struct chase_hip_ctx {
     // (2*F*m*n*k, F = 4 complex) and flops the matrix cores executed (3/4 of it for three-multiplication launches)
     double flops_model[3] = {0, 0, 0}, flops_exec[3] = {0, 0, 0};
     unsigned long long gemm_calls[3] = {0, 0, 0};
+    int gemm_min_rounds = 0;          // > 0: products share the chip with a collective (chase_hip_ctx_set_gemm_min_rounds)
     void* ws = nullptr;          // split-K slabs, grown on demand
     size_t ws_bytes = 0;
     enum { BUF_TINV = 0, BUF_PANEL, BUF_SCAL, BUF_LAMBDA, NBUF };

@@ -826,7 +826,24 @@ static int choose_tail_sk(long tail, long slots, int nkt, size_t slab_bytes, siz
     return sk;
 }
 
-struct LaunchInfo { int device; double* exec_flops; };     // per-device attribute flags, executed-flop accounting
+// per-device attribute flags, executed-flop accounting; min_rounds > 0: a product with fewer than min_rounds tiles per
+// workgroup slot is cut along K until it has that many pieces per slot (see forced_split)
+struct LaunchInfo { int device; double* exec_flops; int min_rounds; };
+
+// Granularity for launches that SHARE the chip with a collective (the panel products of the pipelined distributed HEMM): a
+// panel is sized to fill the 512 workgroup slots exactly once, and the kernel's two workgroups per CU leave no registers or
+// LDS for another kernel's waves, so an all-reduce kernel that needs a few CUs displaces whole tiles into a second round -
+// the panel would take twice as long.  Cut into `sk` K pieces per tile (raw slabs + the fixed-order reduction of the tail
+// path), the displaced work is a fraction of a tile.  Returns the split (1: leave the automatic decomposition alone).
+static int forced_split(long tiles, long slots, int nkt, size_t slab_bytes, size_t ws_bytes, int min_rounds)
+{
+    if (min_rounds <= 0 || tiles <= 0 || tiles >= (long)min_rounds * slots) return 1;
+    long sk = ((long)min_rounds * slots + tiles - 1) / tiles;
+    sk = std::min<long>(sk, 8);
+    sk = std::min<long>(sk, nkt / 64);                                        // pieces of at least 64 K steps
+    sk = std::min<long>(sk, (long)(std::min(ws_bytes, GEMM_WS_CAP) / (slab_bytes * (size_t)tiles)));
+    return sk < 2 ? 1 : (int)sk;
+}
 constexpr int MAX_DEVICES = 64;
 
 template <bool CPLX, bool OPA_C, int TAG>
@@ -861,6 +878,10 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
         if (slab_bytes * (size_t)tail * sk > ws_bytes) sk = choose_tail_sk(tail, slots, nkt, slab_bytes, ws_bytes);
     }
     if (sk <= 1) { full = tiles; tail = 0; sk = 1; }         // nothing to split: every tile is a whole tile
+    if (ws != nullptr) {
+        const int fs = forced_split(tiles, slots, nkt, slab_bytes, ws_bytes, li.min_rounds);
+        if (fs > 1) { full = 0; tail = tiles; sk = fs; }     // shared-chip launch: every tile in K pieces
+    }
     int kchunk = ((nkt + sk - 1) / sk) * C_::BK;
     a.full_tiles = (int)full; a.tail_sk = sk; a.tail_kchunk = kchunk; a.slabs = ws;
     // global_load_lds moves 16 bytes per lane: complex elements always qualify, real ones need even leading dimensions
@@ -1006,40 +1027,38 @@ static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha,
 // rounds of the chip (the ragged-column launch is K-split over the whole chip); the caller grows its workspace to this
 // on demand instead of holding a fixed allocation
 template <bool CPLX, bool OPA_C>
-static size_t ws_need(int m, int n, int k, int num_cu)
+static size_t ws_need(int m, int n, int k, int num_cu, int min_rounds)
 {
     using C_ = Cfg<CPLX, OPA_C>;
     if (m <= 0 || n <= 0 || k <= 0) return 0;
     const size_t slab_bytes = (size_t)C_::BM * C_::BN * sizeof(double) * C_::EPT;
     const long slots = 2L * num_cu;
     const int nkt = (k + C_::BK - 1) / C_::BK;
-    auto part = [&](int nn) -> size_t {
-        const long tiles = (long)((m + C_::BM - 1) / C_::BM) * ((nn + C_::BN - 1) / C_::BN);
+    auto for_tiles = [&](long tiles) -> size_t {
+        const int fs = forced_split(tiles, slots, nkt, slab_bytes, GEMM_WS_CAP, min_rounds);
+        if (fs > 1) return slab_bytes * (size_t)tiles * fs;
         const long tail = tiles % slots;
         if (tail == 0) return 0;
         const int sk = choose_tail_sk(tail, slots, nkt, slab_bytes, GEMM_WS_CAP);
         return sk > 1 ? slab_bytes * (size_t)tail * sk : 0;
     };
+    auto part = [&](int nn) -> size_t { return for_tiles((long)((m + C_::BM - 1) / C_::BM) * ((nn + C_::BN - 1) / C_::BN)); };
     const int rem = n % C_::BN;
     if (n > C_::BN && rem != 0 && rem <= C_::BN - 16) {
         const int bnu = uniform_tile_cols<CPLX, OPA_C>(m, n, k);
-        if (bnu > 0) {
-            const long tiles = (long)((m + C_::BM - 1) / C_::BM) * ((n + bnu - 1) / bnu);
-            const long tail = tiles % slots;
-            if (tail == 0) return 0;
-            const int sk = choose_tail_sk(tail, slots, nkt, slab_bytes, GEMM_WS_CAP);
-            return sk > 1 ? slab_bytes * (size_t)tail * sk : 0;
-        }
+        if (bnu > 0) return for_tiles((long)((m + C_::BM - 1) / C_::BM) * ((n + bnu - 1) / bnu));
         return std::max(part(n - rem), part(rem));
     }
     return part(n);
 }
 
-size_t gemm_f64_ws_need(bool cplx, char opA, int m, int n, int k, int num_cu)
+size_t gemm_f64_ws_need(bool cplx, char opA, int m, int n, int k, int num_cu, int min_rounds)
 {
     const bool opc = (opA == 'C' || opA == 'c' || opA == 'T' || opA == 't');
-    if (!cplx) return opc ? ws_need<false, true>(m, n, k, num_cu) : ws_need<false, false>(m, n, k, num_cu);
-    auto need = [&](int mm, int kk) { return opc ? ws_need<true, true>(mm, n, kk, num_cu) : ws_need<true, false>(mm, n, kk, num_cu); };
+    if (!cplx) return opc ? ws_need<false, true>(m, n, k, num_cu, min_rounds) : ws_need<false, false>(m, n, k, num_cu, min_rounds);
+    auto need = [&](int mm, int kk) {
+        return opc ? ws_need<true, true>(mm, n, kk, num_cu, min_rounds) : ws_need<true, false>(mm, n, kk, num_cu, min_rounds);
+    };
     size_t r = need(m, k);
     // a filter product with ragged rims may be cut into a 3M bulk and two thin 4M rims (launch_gemm): cover those shapes too
     const bool split = opc ? split3m_applies<true, true>(m, n, k, true) : split3m_applies<true, false>(m, n, k, true);
@@ -1054,10 +1073,10 @@ size_t gemm_f64_ws_need(bool cplx, char opA, int m, int n, int k, int num_cu)
 
 int gemm_f64(hipStream_t st, bool cplx, char opA, int m, int n, int k, const double* alpha, const double* A, long lda,
              const double* B, long ldb, const double* beta, double* C, long ldc, double* ws, size_t ws_bytes, int num_cu,
-             int tag, int device, double* exec_flops)
+             int tag, int device, double* exec_flops, int min_rounds)
 {
     const bool opc = (opA == 'C' || opA == 'c' || opA == 'T' || opA == 't');
-    const LaunchInfo li{device, exec_flops};
+    const LaunchInfo li{device, exec_flops, min_rounds};
     static const bool rr3m = [] { const char* e = getenv("CHASE_HIP_GEMM3M_RR"); return e && atoi(e) != 0; }();
     const bool allow2 = (tag == 2) && rr3m;
 #define CHASE_GEMM_DISPATCH(CP, OC)                                                                                    \

@@ -10,12 +10,13 @@ namespace chase_hip {
 // ws/ws_bytes: optional device workspace for deterministic split-K.
 // tag: 1 = Chebyshev-filter product (own kernel symbol; complex products may take the three-multiplication scheme),
 // 2 = H-times-block product outside the filter, 0 = everything else.  device: ordinal the stream lives on (per-device
-// kernel attributes).  exec_flops (optional): += the flops the matrix cores execute for this product.
+// kernel attributes).  exec_flops (optional): += the flops the matrix cores execute for this product.  min_rounds > 0: the
+// launch shares the chip with a collective - products with fewer tiles than min_rounds per workgroup slot are cut along K.
 int gemm_f64(hipStream_t st, bool cplx, char opA, int m, int n, int k, const double* alpha, const double* A, long lda,
              const double* B, long ldb, const double* beta, double* C, long ldc, double* ws, size_t ws_bytes,
-             int num_cu, int tag = 0, int device = 0, double* exec_flops = nullptr);
+             int num_cu, int tag = 0, int device = 0, double* exec_flops = nullptr, int min_rounds = 0);
 constexpr size_t GEMM_WS_CAP = (size_t)640 << 20;         // upper bound of the split-K workspace
-size_t gemm_f64_ws_need(bool cplx, char opA, int m, int n, int k, int num_cu);
+size_t gemm_f64_ws_need(bool cplx, char opA, int m, int n, int k, int num_cu, int min_rounds = 0);
 int gemm3m_enabled();
 void gemm3m_set(int on);
 

@@ -11,12 +11,12 @@ int chase_hip_ctx::gemm(bool cplx, char opA, int m, int n, int k, const double* 
     if (m <= 0 || n <= 0) return 0;
     // workspace: what this shape's tail split can use (never the whole fixed cap up front), at least 8 MB so that the
     // ragged-column launch is always available
-    const size_t need = std::max(chase_hip::gemm_f64_ws_need(cplx, opA, m, n, k, num_cu), (size_t)8 << 20);
+    const size_t need = std::max(chase_hip::gemm_f64_ws_need(cplx, opA, m, n, k, num_cu, gemm_min_rounds), (size_t)8 << 20);
     int rc = ensure_ws((need + ((size_t)32 << 20) - 1) & ~(((size_t)32 << 20) - 1));
     if (rc) return rc;
     const int ph = (phase >= 0 && phase <= 2) ? phase : 0;
     int e = chase_hip::gemm_f64(stream, cplx, opA, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, (double*)ws, ws_bytes,
-                                num_cu, phase, device, &flops_exec[ph]);
+                                num_cu, phase, device, &flops_exec[ph], gemm_min_rounds);
     if (e) return chase_hip::hip_fail((hipError_t)e, "gemm launch");
     flops_model[ph] += 2.0 * (cplx ? 4.0 : 1.0) * m * (double)n * k;
     ++gemm_calls[ph];

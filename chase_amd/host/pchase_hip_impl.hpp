@@ -508,6 +508,10 @@ protected:
         const T* Hb = bAc ? dHbac_ : dH_;
         const std::size_t ldb = bAc ? ldhbac_ : ldh_;
         const bool pipe = pipelined && pipeline_ && chase_hip_grid_group_active(grid_, group) != 0;
+        // the panel products run beside the previous panel's all-reduce: finer work units, so that the CUs the collective
+        // takes displace a fraction of a tile (chase_hip_ctx_set_gemm_min_rounds; CHASE_HIP_PANEL_ROUNDS, 0 = off)
+        static const int panel_rounds = [] { const char* e = std::getenv("CHASE_HIP_PANEL_ROUNDS"); return e ? std::atoi(e) : 4; }();
+        if (pipe) hip_ok(chase_hip_ctx_set_gemm_min_rounds(ctx_, panel_rounds), "gemm_min_rounds");
         std::size_t c = c0;
         while (c < c0 + nc) {
             const std::size_t fp = c / panel_;                                 // fixed panel index
@@ -520,6 +524,7 @@ protected:
             if (pipe) coll(chase_hip_grid_event_record(grid_, (int)fp));
             c = cend;
         }
+        if (pipe) hip_ok(chase_hip_ctx_set_gemm_min_rounds(ctx_, 0), "gemm_min_rounds");
     }
     // X <- S X on the local rows of a column-type / row-type block (global rows >= N/2 change sign)
     void flip_coltype(T* X, std::size_t ncols, double s = -1.0)

@@ -89,6 +89,11 @@ int chase_hip_hbm_copy_peak(chase_hip_ctx* ctx, size_t bytes, double* gbps);
  * scheme).  Complex products of phase 1 may use the three-multiplication scheme (see chase_hip_gemm3m_enabled);
  * 0 = everything else (always four multiplications) */
 int chase_hip_ctx_set_phase(chase_hip_ctx* ctx, int phase);
+/* Granularity of the following products: rounds > 0 says they share the chip with a collective on another stream (the panel
+ * products of the pipelined distributed HEMM) - a product with fewer than `rounds` output tiles per workgroup slot is then cut
+ * along K into that many pieces per slot, so that the CUs the collective's kernel takes displace a fraction of a tile and
+ * not a whole one; 0 (default) = the automatic decomposition.  Results stay deterministic (fixed-order slab reduction). */
+int chase_hip_ctx_set_gemm_min_rounds(chase_hip_ctx* ctx, int rounds);
 
 /* ---- on-device input generators (global-index addressed, shard-safe) ------------------------------------------ */
 /* N(0,1) fill (Philox4x32-10 + Box-Muller).  Replaces cuda/random_normal_distribution.cu:21-95 (initVecs on GPU) */

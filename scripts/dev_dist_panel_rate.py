@@ -9,6 +9,7 @@ with Context(0) as ctx:
     dA = ctx.empty((rows, cols), np.complex128)
     check(lib.chase_hip_fill_normal(ctx.h, 1, rows, cols, dA.ptr, rows, 0, 0, rows, 1), "fill")
     lib.chase_hip_ctx_set_phase(ctx.h, 1)
+    lib.chase_hip_ctx_set_gemm_min_rounds(ctx.h, int(os.environ.get("DEV_MIN_ROUNDS", "0")))
     for op, m, k in (("N", rows, cols), ("C", cols, rows)):
         dB = ctx.empty((k, nfull), np.complex128); dC = ctx.empty((m, nfull), np.complex128)
         check(lib.chase_hip_fill_normal(ctx.h, 1, k, nfull, dB.ptr, k, 0, 0, k, 2), "fill")
@@ -21,6 +22,6 @@ with Context(0) as ctx:
             ctx.timer_start()
             for _ in range(3): sweep()
             ms = ctx.timer_stop() / 3
-            print(f"op={op} m={m} k={k}: 2560 columns in panels of {w:4d}: {ms:7.2f} ms = {2.0*4*m*k*nfull/(ms*1e-3)/1e12:6.2f} TFLOP/s (model)", flush=True)
+            print(f"op={op} m={m} k={k}: 2560 columns in panels of {w:4d} (min_rounds {os.environ.get('DEV_MIN_ROUNDS', '0')}): {ms:7.2f} ms = {2.0*4*m*k*nfull/(ms*1e-3)/1e12:6.2f} TFLOP/s (model)", flush=True)
         dB.free(); dC.free()
     lib.chase_hip_ctx_set_phase(ctx.h, 0)

@@ -488,6 +488,37 @@ def test_filter_gemm_is_bitwise_reproducible(ctx):
         lib.chase_hip_ctx_set_phase(ctx.h, 0)
 
 
+@pytest.mark.parametrize("cplx,op", [(True, "N"), (True, "C"), (False, "N")])
+def test_gemm_in_k_pieces_for_shared_chip_launches(ctx, cplx, op):
+    """chase_hip_ctx_set_gemm_min_rounds (the panel products of the pipelined distributed HEMM): a product with fewer tiles than
+    `rounds` per workgroup slot runs as K pieces + the fixed-order slab reduction: same values as numpy, identical bits from
+    launch to launch, and the same tolerance-level result as the undivided product."""
+    from chase_amd.capi import lib
+    rng = np.random.default_rng(21)
+    m, k, n = 16384, 2048, (256 if cplx else 512)      # 128 x 4 tiles = exactly one round of the 512 slots: undivided by default
+    A = rnd(rng, (m, k) if op == "N" else (k, m), cplx)
+    B, Cin = rnd(rng, (k, n), cplx), rnd(rng, (m, n), cplx)
+    dA, dB = ctx.array(A), ctx.array(B)
+    ref = 0.3 * ((A if op == "N" else A.conj().T) @ B) - 0.5 * Cin
+    scale = np.abs(A).sum(axis=1).max() if op == "N" else np.abs(A).sum(axis=0).max()
+    outs = {}
+    for phase in (1, 0):
+        lib.chase_hip_ctx_set_phase(ctx.h, phase)
+        for rounds in (0, 4):
+            lib.chase_hip_ctx_set_gemm_min_rounds(ctx.h, rounds)
+            res = []
+            for rep in range(3):
+                dC = ctx.array(Cin)
+                ctx.gemm(op, m, n, k, 0.3, dA.ptr, A.shape[0], dB.ptr, k, -0.5, dC.ptr, m, cplx)
+                res.append(dC.download()); dC.free()
+            assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
+            assert np.max(np.abs(res[0] - ref)) <= 64 * EPS * scale * np.abs(B).max()
+            outs[(phase, rounds)] = res[0]
+        assert not np.array_equal(outs[(phase, 0)], outs[(phase, 4)])       # the pieces really are summed in another order
+    lib.chase_hip_ctx_set_gemm_min_rounds(ctx.h, 0)
+    lib.chase_hip_ctx_set_phase(ctx.h, 0)
+
+
 @pytest.mark.parametrize("op", ["N", "C"])
 @pytest.mark.parametrize("m,k,n", [(1153, 1001, 96), (1280, 1003, 133), (1100, 1024, 64)])
 def test_filter_gemm_of_arbitrary_size_uses_3m_for_the_bulk(ctx, op, m, k, n):
