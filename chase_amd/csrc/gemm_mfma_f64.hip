@@ -24,8 +24,13 @@
 //     The K order inside an 8-deep (real) chunk is permuted (MFMA s takes k = 2q+s) identically for both operands.
 //   * K-contiguous tiles are stored [k-unit][row ^ k-unit] (XOR on the low 3 bits) so that the staging ds_write_b128
 //     and the fragment ds_read_b128 are both conflict-free.
-//   * complex: 4 real MFMAs per (re,im) tile step on planar fragments held in registers (interleaved in HBM/LDS).
-//   * global -> register -> LDS staging, double-buffered LDS, one barrier per K step, two workgroups per CU.
+//   * complex: 4 real MFMAs per (re,im) tile step on planar fragments held in registers (interleaved in HBM/LDS); filter
+//     products: 3 real MFMAs (the "3M" scheme, see the kernel's M3 parameter).
+//   * global -> LDS by LDS-DMA (global_load_lds_dwordx4 in its scalar-base + 32-bit lane-offset form, inline assembly: no
+//     64-bit vector address arithmetic, which on gfx950 runs on the fp64 matrix unit), 3 (complex) / 2 (real) LDS stages, the
+//     copies of the next tile hung one by one under the MFMA groups of the current one, software-pipelined fragment reads,
+//     one barrier per K step, two workgroups per CU; ragged M / unaligned operands / partial K tiles fall back to a
+//     register-staged path (global -> register -> LDS) in the same kernel.  profiles/r02_mfma_f64_issue.txt has the numbers.
 //   * XCD-aware tile order: consecutive logical tiles (same A row panel, different column panels) run on one XCD
 //     so the streamed H panel is fetched once per XCD L2.
 //   * deterministic split-K (slabs + fixed-order reduce) for the short-and-fat Gram products (k = N >> m, n).
