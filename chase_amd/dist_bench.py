@@ -14,6 +14,62 @@ import time
 import numpy as np
 
 
+def comm_probe(ctx, grid, dH, m_loc, n_loc, cplx, nevex, panel=256, reps=5):
+    """Diagnostics for the multi-GPU runs (this session could only run them through size-1 communicators): what the filter's
+    all-reduces cost on their own, and what one panel product of the pipelined HEMM costs alone, beside an all-reduce of the
+    previous panel, and with the K-piece granularity switched off.  Every rank takes part; rank 0 reports."""
+    from .capi import lib, check
+    E = 2 if cplx else 1
+    dt = np.complex128 if cplx else np.float64
+    out = {"panel_cols": panel, "reps": reps}
+    from .dist import ROW, COL                          # CHASE_HIP_ROW / CHASE_HIP_COL (include/chase_hip_grid.h)
+
+    def timed(fn):
+        fn()
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(reps):
+            fn()
+        return ctx.timer_stop() / reps
+
+    for name, group, rows, size in (("col_group", COL, n_loc, grid.nprow), ("row_group", ROW, m_loc, grid.npcol)):
+        if not lib.chase_hip_grid_group_active(grid.h, group):
+            continue
+        for label, cols in (("panel", panel), ("full_width", nevex)):
+            buf = ctx.empty((rows, cols), dt)
+            check(lib.chase_hip_fill_normal(ctx.h, int(cplx), rows, cols, buf.ptr, rows, 0, 0, rows, 7), "fill")
+            ms = timed(lambda: check(lib.chase_hip_grid_allreduce(grid.h, group, buf.ptr, rows * cols * E, 0), "allreduce"))
+            nbytes = rows * cols * E * 8
+            out[f"{name}_{label}_allreduce"] = {"ranks": size, "bytes": nbytes, "ms": ms,
+                                                 "algbw_GBps": nbytes / (ms * 1e-3) / 1e9,
+                                                 "busbw_GBps": nbytes * 2.0 * (size - 1) / max(size, 1) / (ms * 1e-3) / 1e9}
+            buf.free()
+    # one panel of the column -> row product (W = H_loc^H V) alone / beside the all-reduce of another panel
+    if lib.chase_hip_grid_group_active(grid.h, COL):
+        V = ctx.empty((m_loc, panel), dt); W = ctx.empty((n_loc, panel), dt); X = ctx.empty((n_loc, panel), dt)
+        check(lib.chase_hip_fill_normal(ctx.h, int(cplx), m_loc, panel, V.ptr, m_loc, 0, 0, m_loc, 8), "fill")
+        check(lib.chase_hip_fill_normal(ctx.h, int(cplx), n_loc, panel, X.ptr, n_loc, 0, 0, n_loc, 9), "fill")
+        lib.chase_hip_ctx_set_phase(ctx.h, 1)
+
+        def gemm():
+            ctx.gemm("C", n_loc, panel, m_loc, 0.5, dH.ptr, m_loc, V.ptr, m_loc, 0.0, W.ptr, n_loc, cplx)
+
+        def both():
+            check(lib.chase_hip_grid_allreduce(grid.h, COL, X.ptr, n_loc * panel * E, 1), "allreduce")
+            gemm()
+            check(lib.chase_hip_grid_wait(grid.h), "grid_wait")
+
+        for rounds in (0, 4):
+            lib.chase_hip_ctx_set_gemm_min_rounds(ctx.h, rounds)
+            out[f"panel_gemm_alone_ms_rounds{rounds}"] = timed(gemm)
+            out[f"panel_gemm_beside_allreduce_ms_rounds{rounds}"] = timed(both)
+        lib.chase_hip_ctx_set_gemm_min_rounds(ctx.h, 0)
+        lib.chase_hip_ctx_set_phase(ctx.h, 0)
+        for a in (V, W, X):
+            a.free()
+    return out
+
+
 def run_distributed(args):
     import torch
     import torch.distributed as dist
@@ -108,6 +164,10 @@ def run_distributed(args):
     tm = torch.tensor([tot["filter_ms"]], dtype=torch.float64)
     dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     tot["model"], tot["exec"], tot["filter_ms"] = float(tw[0]), float(tw[1]), float(tm[0])
+    probe = None
+    if is_rccl and not pseudo and not getattr(args, "no_probe", False):
+        dist.barrier()
+        probe = comm_probe(ctx, grid, dH, rl.count(myrow), cl.count(mycol), cplx, nevex)
     out = None
     if rank == 0:
         out = {
@@ -143,6 +203,7 @@ def run_distributed(args):
                                           "; filter time includes the row/column all-reduces"),
         }
         out["roofline"]["whole_run"] = B.whole_run_object(tot, world)
+        out["comm_probe"] = probe
     s.close()
     grid.close()
     del dH
