@@ -165,7 +165,8 @@ def run_distributed(args):
     dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     tot["model"], tot["exec"], tot["filter_ms"] = float(tw[0]), float(tw[1]), float(tm[0])
     probe = None
-    if is_rccl and not pseudo and not getattr(args, "no_probe", False):
+    # (the host-callback test transport runs it only on request: CHASE_HIP_PROBE_HOST=1, to exercise the multi-rank code path)
+    if (is_rccl or os.environ.get("CHASE_HIP_PROBE_HOST") == "1") and not pseudo and not getattr(args, "no_probe", False):
         dist.barrier()
         probe = comm_probe(ctx, grid, dH, rl.count(myrow), cl.count(mycol), cplx, nevex)
     out = None
