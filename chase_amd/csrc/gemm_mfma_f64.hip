@@ -951,8 +951,10 @@ static int uniform_tile_cols(int m, int n, int k)
     if (mode == 0 || (!CPLX && mode != 2)) return 0;      // measured (profiles/r02_hemm_sweep.txt): a gain for the complex kernels only
     const int ng = (n + 15) / 16, ntiles = (ng + C_::TN - 1) / C_::TN, g = (ng + ntiles - 1) / ntiles;
     if (g >= C_::TN) return 0;
-    const double t_group = 2.0 * (CPLX ? 3.0 : 1.0) * m * (double)k * 16.0 / 68.0e12;    // executed flops at ~68 TFLOP/s
-    const double t_pass = (double)m * k * C_::EPT * 8.0 / 4.7e12;                          // one stream over A
+    // measured (profiles/r02_hemm_sweep.txt, r02_mfma_f64_issue.txt): ~73 TFLOP/s executed on whole tiles; a launch that only
+    // streams A (16 columns) moves it at 6.0 TB/s (N = 32768: 2.87 ms, N = 65536: 11.5 ms)
+    const double t_group = 2.0 * (CPLX ? 3.0 : 1.0) * m * (double)k * 16.0 / 73.0e12;
+    const double t_pass = (double)m * k * C_::EPT * 8.0 / 6.0e12;
     const int whole = n / C_::BN, rem_groups = (n % C_::BN + 15) / 16;
     const double cost_split = whole * C_::TN * t_group + std::max(rem_groups * t_group, t_pass) + 10e-6;
     const double cost_uniform = std::max((double)ntiles * g * t_group, t_pass);
