@@ -1,0 +1,58 @@
+"""bench.py on the GPU: the JSON line of a short run (config 2, one solve) keeps the driver's contract, single-GPU and through
+the multi-rank entry point with the ranks sharing the one GPU (host test transport)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline")
+
+
+def run_bench(*args, env=None):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env or {})))
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    last = p.stdout.strip().splitlines()[-1]
+    return json.loads(last)                                   # the JSON line is the LAST line of stdout
+
+
+def check_common(d, n_gpus, steps, warmup):
+    for k in KEYS:
+        assert k in d, k
+    assert d["metric"] == "chebyshev_filter_hemm_gflops" and d["unit"] == "GFLOP/s" and d["higher_is_better"] is True
+    assert (d["n_gpus"], d["steps"], d["warmup"]) == (n_gpus, steps, warmup)
+    assert d["scaling"] == "strong" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "complex f64"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
+    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert d["converged"] is True and d["spectrum_check"]["ok"] is True
+    assert len(d["timed"]["iterations"]) == steps
+    assert d["ms_per_step"] > 0 and d["value"] > 0
+
+
+def test_single_gpu_line_keeps_the_contract():
+    d = run_bench("--workload", "cfg2", "--steps", "9", "--warmup", "0", "--cpu-budget", "3")
+    check_common(d, 1, 9, 0)
+    assert d["iterations_per_solve"] == 9 and d["filtered_vecs_per_solve"] == 101708        # the oracle's counts for config 2
+    assert d["roofline"]["frac"] > 0.5                                                       # a fallback path would not get here
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "extrapolated" in c["sample"]
+    for probe in ("roofline_4m", "roofline_3m_fullwidth"):
+        assert 0.0 < d[probe]["frac"] <= 1.0
+    assert d["roofline"]["executed_over_model"] == pytest.approx(0.75, abs=0.02)             # 3M filter products
+
+
+def test_multi_rank_entry_point_on_one_gpu():
+    d = run_bench("--gpus", "4", "--workload", "cfg2", "--steps", "9", "--warmup", "0", "--no-cpu-baseline",
+                  env={"CHASE_HIP_TRANSPORT": "host", "CHASE_HIP_PROBE_HOST": "1"})
+    check_common(d, 4, 9, 0)
+    assert d["config"]["grid"] == "2x2" and d["config"]["transport"] == "host"
+    assert d["iterations_per_solve"] == 9
+    p = d["comm_probe"]
+    assert p["col_group_panel_allreduce"]["ranks"] == 2 and p["panel_gemm_alone_ms_rounds4"] > 0
