@@ -35,6 +35,11 @@ using namespace chase_hip;
 extern "C" {
 
 const char* chase_hip_version(void) { return "chase_hip 0.1 (gfx950)"; }
+int chase_hip_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 const char* chase_hip_last_error(void) { return g_last_error.c_str(); }
 
 int chase_hip_ctx_create(chase_hip_ctx** out, int device, void* stream)

@@ -840,16 +840,60 @@ struct LaunchInfo { int device; double* exec_flops; int min_rounds; };
 // LDS for another kernel's waves, so an all-reduce kernel that needs a few CUs displaces whole tiles into a second round -
 // the panel would take twice as long.  Cut into `sk` K pieces per tile (raw slabs + the fixed-order reduction of the tail
 // path), the displaced work is a fraction of a tile.  Returns the split (1: leave the automatic decomposition alone).
-static int forced_split(long tiles, long slots, int nkt, size_t slab_bytes, size_t ws_bytes, int min_rounds)
+static int forced_split(long tiles, long slots, int nkt, size_t slab_bytes, int min_rounds)
 {
     if (min_rounds <= 0 || tiles <= 0 || tiles >= (long)min_rounds * slots) return 1;
     long sk = ((long)min_rounds * slots + tiles - 1) / tiles;
     sk = std::min<long>(sk, 8);
     sk = std::min<long>(sk, nkt / 64);                                        // pieces of at least 64 K steps
-    sk = std::min<long>(sk, (long)(std::min(ws_bytes, GEMM_WS_CAP) / (slab_bytes * (size_t)tiles)));
+    sk = std::min<long>(sk, (long)(GEMM_WS_CAP / (slab_bytes * (size_t)tiles)));
     return sk < 2 ? 1 : (int)sk;
 }
 constexpr int MAX_DEVICES = 64;
+
+// The decomposition of ONE launch (m x n x k in column tiles of bn_cols columns): whole tiles, tail tiles cut into sk K
+// pieces, the slab bytes that needs.  A function of the shape, the chip and min_rounds ONLY - the split, and with it the
+// summation order, never depends on how far a caller's workspace happens to have grown.  The one place both the launcher
+// (launch_gemm_part) and the workspace sizing (gemm_f64_ws_need) take it from.
+struct PartPlan { long full, tail; int sk; size_t ws_bytes; };
+template <bool CPLX, bool OPA_C>
+static PartPlan plan_part(int m, int n, int k, int bn_cols, int num_cu, int min_rounds)
+{
+    using C_ = Cfg<CPLX, OPA_C>;
+    if (bn_cols <= 0 || bn_cols > C_::BN) bn_cols = C_::BN;
+    const long tiles = (long)((m + C_::BM - 1) / C_::BM) * ((n + bn_cols - 1) / bn_cols);
+    const long slots = 2L * num_cu;                          // two workgroups per CU
+    const int nkt = (k + C_::BK - 1) / C_::BK;
+    const size_t slab_bytes = (size_t)C_::BM * C_::BN * sizeof(double) * C_::EPT;
+    PartPlan p{tiles, 0, 1, 0};
+    if (m <= 0 || n <= 0 || k <= 0) return p;
+    const int fs = forced_split(tiles, slots, nkt, slab_bytes, min_rounds);
+    if (fs > 1) { p.full = 0; p.tail = tiles; p.sk = fs; }  // shared-chip launch: every tile in K pieces
+    else {
+        // cost of the tail in units of "one tile on one slot": ceil(tail*sk/slots)/sk rounds, slightly penalising big sk
+        const long tail = tiles % slots;
+        const int sk = tail > 0 ? choose_tail_sk(tail, slots, nkt, slab_bytes, GEMM_WS_CAP) : 1;
+        if (sk > 1) { p.full = tiles - tail; p.tail = tail; p.sk = sk; }      // else: every tile is a whole tile
+    }
+    p.ws_bytes = p.tail > 0 ? slab_bytes * (size_t)p.tail * p.sk : 0;
+    return p;
+}
+
+// How a width n is covered by launches (launch_gemm_cols): one launch of whole tiles (+ guarded last tile), one launch of
+// "uniform ragged" tiles of bnu columns, or whole tiles + the ragged rest in a launch of its own.
+struct ColsPlan { int bnu; int n1; };                        // bnu > 0: uniform; n1 > 0: split at column n1; else single
+template <bool CPLX, bool OPA_C> static int uniform_tile_cols(int m, int n, int k);
+template <bool CPLX, bool OPA_C>
+static ColsPlan plan_cols(int m, int n, int k)
+{
+    using C_ = Cfg<CPLX, OPA_C>;
+    const int rem = n % C_::BN;
+    const bool balanced = (C_::WAVES_N == 1);          // all waves span the tile width: skipped groups cost nobody
+    if (!(balanced && n > C_::BN && rem != 0 && rem <= C_::BN - 16)) return ColsPlan{0, 0};
+    const int bnu = uniform_tile_cols<CPLX, OPA_C>(m, n, k);
+    if (bnu > 0) return ColsPlan{bnu, 0};              // every column tile gets the same number of 16-column groups
+    return ColsPlan{0, n - rem};
+}
 
 template <bool CPLX, bool OPA_C, int TAG>
 static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* alpha, const double* A, long lda,
@@ -868,25 +912,14 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
     a.group_rows = group_rows;
     a.alpha_re = alpha[0]; a.alpha_im = CPLX ? alpha[1] : 0.0;
     a.beta_re = beta[0];   a.beta_im = CPLX ? beta[1] : 0.0;
-    const long tiles = (long)a.gm * a.gn;
-    const long slots = 2L * num_cu;                          // two workgroups per CU
     const int nkt = (k + C_::BK - 1) / C_::BK;
-    long full = (tiles / slots) * slots;
-    long tail = tiles - full;
-    int sk = 1;
-    const size_t slab_bytes = (size_t)C_::BM * C_::BN * sizeof(double) * C_::EPT;
-    // cost of the tail in units of "one tile on one slot": ceil(tail*sk/slots)/sk rounds, slightly penalising big sk
-    // (chosen against the fixed workspace cap, so the split - and with it the summation order - of a given shape does not
-    // depend on how far the caller's workspace happens to have grown; callers size it with gemm_f64_ws_need)
-    if (tail > 0 && ws != nullptr) {
-        sk = choose_tail_sk(tail, slots, nkt, slab_bytes, GEMM_WS_CAP);
-        if (slab_bytes * (size_t)tail * sk > ws_bytes) sk = choose_tail_sk(tail, slots, nkt, slab_bytes, ws_bytes);
-    }
-    if (sk <= 1) { full = tiles; tail = 0; sk = 1; }         // nothing to split: every tile is a whole tile
-    if (ws != nullptr) {
-        const int fs = forced_split(tiles, slots, nkt, slab_bytes, ws_bytes, li.min_rounds);
-        if (fs > 1) { full = 0; tail = tiles; sk = fs; }     // shared-chip launch: every tile in K pieces
-    }
+    // without a workspace nothing can be split; with one, the plan's slabs must fit - callers size the workspace with
+    // gemm_f64_ws_need, which takes its numbers from the same plan
+    PartPlan pl = plan_part<CPLX, OPA_C>(m, n, k, bn_cols, num_cu, li.min_rounds);
+    if (ws == nullptr) pl = PartPlan{(long)a.gm * a.gn, 0, 1, 0};
+    if (pl.ws_bytes > ws_bytes) return (int)hipErrorInvalidValue;       // never split differently to fit: refuse
+    const long full = pl.full, tail = pl.tail;
+    const int sk = pl.sk;
     int kchunk = ((nkt + sk - 1) / sk) * C_::BK;
     a.full_tiles = (int)full; a.tail_sk = sk; a.tail_kchunk = kchunk; a.slabs = ws;
     // global_load_lds moves 16 bytes per lane: complex elements always qualify, real ones need even leading dimensions
@@ -973,16 +1006,14 @@ static int launch_gemm_cols(hipStream_t st, int m, int n, int k, const double* a
 {
     using C_ = Cfg<CPLX, OPA_C>;
     constexpr int EPT = C_::EPT;
-    const int rem = n % C_::BN;
-    const bool balanced = (C_::WAVES_N == 1);          // all waves span the tile width: skipped groups cost nobody
-    if (balanced && n > C_::BN && rem != 0 && rem <= C_::BN - 16 && ws != nullptr) {
-        const int bnu = uniform_tile_cols<CPLX, OPA_C>(m, n, k);
-        if (bnu > 0)       // every column tile gets the same number of 16-column groups: one launch, one pass over A
-            return launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, allow3m, li, bnu);
-        const int n1 = n - rem;
+    const ColsPlan cp = ws != nullptr ? plan_cols<CPLX, OPA_C>(m, n, k) : ColsPlan{0, 0};
+    if (cp.bnu > 0)        // one launch, one pass over A
+        return launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, allow3m, li, cp.bnu);
+    if (cp.n1 > 0) {
+        const int n1 = cp.n1;
         int rc = launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n1, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, allow3m, li);
         if (rc) return rc;
-        return launch_gemm_part<CPLX, OPA_C, TAG>(st, m, rem, k, alpha, A, lda, B + (long)n1 * ldb * EPT, ldb, beta,
+        return launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n - n1, k, alpha, A, lda, B + (long)n1 * ldb * EPT, ldb, beta,
                                                   C + (long)n1 * ldc * EPT, ldc, ws, ws_bytes, num_cu, allow3m, li);
     }
     return launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, allow3m, li);
@@ -1036,27 +1067,12 @@ static int launch_gemm(hipStream_t st, int m, int n, int k, const double* alpha,
 template <bool CPLX, bool OPA_C>
 static size_t ws_need(int m, int n, int k, int num_cu, int min_rounds)
 {
-    using C_ = Cfg<CPLX, OPA_C>;
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    const size_t slab_bytes = (size_t)C_::BM * C_::BN * sizeof(double) * C_::EPT;
-    const long slots = 2L * num_cu;
-    const int nkt = (k + C_::BK - 1) / C_::BK;
-    auto for_tiles = [&](long tiles) -> size_t {
-        const int fs = forced_split(tiles, slots, nkt, slab_bytes, GEMM_WS_CAP, min_rounds);
-        if (fs > 1) return slab_bytes * (size_t)tiles * fs;
-        const long tail = tiles % slots;
-        if (tail == 0) return 0;
-        const int sk = choose_tail_sk(tail, slots, nkt, slab_bytes, GEMM_WS_CAP);
-        return sk > 1 ? slab_bytes * (size_t)tail * sk : 0;
-    };
-    auto part = [&](int nn) -> size_t { return for_tiles((long)((m + C_::BM - 1) / C_::BM) * ((nn + C_::BN - 1) / C_::BN)); };
-    const int rem = n % C_::BN;
-    if (n > C_::BN && rem != 0 && rem <= C_::BN - 16) {
-        const int bnu = uniform_tile_cols<CPLX, OPA_C>(m, n, k);
-        if (bnu > 0) return for_tiles((long)((m + C_::BM - 1) / C_::BM) * ((n + bnu - 1) / bnu));
-        return std::max(part(n - rem), part(rem));
-    }
-    return part(n);
+    auto part = [&](int nn, int bn_cols) { return plan_part<CPLX, OPA_C>(m, nn, k, bn_cols, num_cu, min_rounds).ws_bytes; };
+    const ColsPlan cp = plan_cols<CPLX, OPA_C>(m, n, k);
+    if (cp.bnu > 0) return part(n, cp.bnu);
+    if (cp.n1 > 0) return std::max(part(cp.n1, 0), part(n - cp.n1, 0));
+    return part(n, 0);
 }
 
 size_t gemm_f64_ws_need(bool cplx, char opA, int m, int n, int k, int num_cu, int min_rounds)

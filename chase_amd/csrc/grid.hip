@@ -55,7 +55,10 @@ int chase_hip_grid::wait_on(hipEvent_t e)
     hipEvent_t a = nullptr, b = nullptr;
     for (hipEvent_t* p : {&a, &b}) {
         if (!ev_pool.empty()) { *p = ev_pool.back(); ev_pool.pop_back(); }
-        else HIPCHK(hipEventCreate(p));
+        else if (hipError_t e = hipEventCreate(p); e != hipSuccess) {
+            if (a) ev_pool.push_back(a);                 // the first event goes back to the pool, not lost
+            return hip_fail(e, "hipEventCreate (exposed-communication bracket)");
+        }
     }
     HIPCHK(hipEventRecord(a, cs));
     HIPCHK(hipStreamWaitEvent(cs, e, 0));

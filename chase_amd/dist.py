@@ -73,16 +73,46 @@ class Layout:
         return ((l // self.nb) * self.p + q) * self.nb + l % self.nb
 
 
+class GlooFabric:
+    """Host-transport back end for ranks that are PROCESSES: torch.distributed (gloo) groups from make_process_groups."""
+
+    def __init__(self, pg, nprow, npcol, rank):
+        myrow, mycol = coords_of(rank, nprow)
+        self.groups = {ROW: pg["row"], COL: pg["col"]}
+        self.ranks = {ROW: [myrow + j * nprow for j in range(npcol)], COL: [i + mycol * nprow for i in range(nprow)]}
+
+    def allreduce(self, group, a):
+        import torch
+        import torch.distributed as dist
+        dist.all_reduce(torch.from_numpy(a), group=self.groups[group])
+
+    def bcast(self, group, a, root):
+        import torch
+        import torch.distributed as dist
+        dist.broadcast(torch.from_numpy(a), src=self.ranks[group][root], group=self.groups[group])
+
+    def sendrecv(self, group, send, peer_send, recv, peer_recv):
+        import torch
+        import torch.distributed as dist
+        ops = []
+        if send is not None:
+            ops.append(dist.P2POp(dist.isend, torch.from_numpy(send), self.ranks[group][peer_send], group=self.groups[group]))
+        if recv is not None:
+            ops.append(dist.P2POp(dist.irecv, torch.from_numpy(recv), self.ranks[group][peer_recv], group=self.groups[group]))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+
+
 class Grid:
     def __init__(self, ctx, nprow, npcol, rank, transport="rccl", pg=None):
         """pg: dict {"world": group, "row": group, "col": group} of torch.distributed groups (host transport /
         bootstrap)."""
-        import torch.distributed as dist
         self.ctx, self.nprow, self.npcol, self.rank = ctx, nprow, npcol, rank
         self.myrow, self.mycol = coords_of(rank, nprow)
         self.transport = transport
         h = c_void_p()
         if transport == "rccl":
+            import torch.distributed as dist
             my_id = C.create_string_buffer(128)
             check(lib.chase_hip_rccl_unique_id(my_id), "rccl_unique_id")
             ids = [None] * (nprow * npcol)
@@ -103,45 +133,40 @@ class Grid:
             check(lib.chase_hip_grid_create_rccl(C.byref(h), ctx.h, nprow, npcol, rank, ids[row_leader],
                                                  ids2[col_leader]), "grid_create_rccl")
         else:
-            import torch
-            groups = {ROW: pg["row"], COL: pg["col"]}
-            row_ranks = [self.myrow + j * nprow for j in range(npcol)]
-            col_ranks = [i + self.mycol * nprow for i in range(nprow)]
+            # host-callback transport (test plumbing): `pg` is either the dict of torch.distributed groups made by
+            # make_process_groups (ranks = processes, payloads through gloo) or any object with
+            # allreduce(group, array) / bcast(group, array, root) / sendrecv(group, send, peer_send, recv, peer_recv)
+            # working in place on float64 numpy views of the pinned staging buffer (ranks = threads of one process,
+            # tests/rank_threads.py)
+            fabric = pg if hasattr(pg, "allreduce") else (GlooFabric(pg, nprow, npcol, rank) if pg is not None else None)
+            self.fabric = fabric
+
+            def _view(buf, count):
+                return np.ctypeslib.as_array(buf, shape=(count,))
 
             def _ar(user, group, buf, count):
                 try:
-                    t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(count,)))
-                    dist.all_reduce(t, group=groups[group])
+                    fabric.allreduce(group, _view(buf, count))
                     return 0
                 except Exception as e:  # pragma: no cover
-                    print("allreduce callback failed:", e, flush=True)
+                    print("allreduce callback failed:", repr(e), flush=True)
                     return 1
 
             def _bc(user, group, buf, count, root):
                 try:
-                    t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(count,)))
-                    src = (row_ranks if group == ROW else col_ranks)[root]
-                    dist.broadcast(t, src=src, group=groups[group])
+                    fabric.bcast(group, _view(buf, count), root)
                     return 0
                 except Exception as e:  # pragma: no cover
-                    print("bcast callback failed:", e, flush=True)
+                    print("bcast callback failed:", repr(e), flush=True)
                     return 1
 
             def _sr(user, group, sbuf, scount, peer_send, rbuf, rcount, peer_recv):
                 try:
-                    ranks = row_ranks if group == ROW else col_ranks
-                    ops = []
-                    if peer_send >= 0 and scount:
-                        ts = torch.from_numpy(np.ctypeslib.as_array(sbuf, shape=(scount,)))
-                        ops.append(dist.P2POp(dist.isend, ts, ranks[peer_send], group=groups[group]))
-                    if peer_recv >= 0 and rcount:
-                        tr = torch.from_numpy(np.ctypeslib.as_array(rbuf, shape=(rcount,)))
-                        ops.append(dist.P2POp(dist.irecv, tr, ranks[peer_recv], group=groups[group]))
-                    for w in (dist.batch_isend_irecv(ops) if ops else []):
-                        w.wait()
+                    fabric.sendrecv(group, _view(sbuf, scount) if peer_send >= 0 and scount else None, peer_send,
+                                    _view(rbuf, rcount) if peer_recv >= 0 and rcount else None, peer_recv)
                     return 0
                 except Exception as e:  # pragma: no cover
-                    print("sendrecv callback failed:", e, flush=True)
+                    print("sendrecv callback failed:", repr(e), flush=True)
                     return 1
 
             self._cb = (AR_FN(_ar), BC_FN(_bc), SR_FN(_sr))          # keep the thunks alive

@@ -14,11 +14,12 @@
 //       MPI, creates the grid and calls the _hip_ form.
 // Everything after init (p?chase_, p?chase_get_eigenpairs_, p?chase_finalize_, p?chase_readHam_ / wrtHam_) has no
 // communicator in its signature and is the reference's name unchanged.
-// Contract like the reference: H is the caller's HOST block (m x n local rows / columns, ldh), copied to the device at
-// init (pChASEGPU copies in initVecs, pchase_gpu.hpp:686); V is the caller's host block of local rows (m x (nev+nex),
-// ld = m; 2*(nev+nex) columns for pseudo-Hermitian problems) — read when mode == 'A', written after the solve (End() copies
-// the eigenvectors back, pchase_gpu.hpp:1010-1018); irsrc / icsrc must be 0 (the reference's distribution functions
-// assume it too, distMatrix.hpp:44-67 numroc with isrcproc = 0).
+// Contract like the reference: H is the caller's HOST block (m x n local rows / columns, ldh), kept by pointer and copied to
+// the device at the start of EVERY solve (pChASEGPU copies in initVecs, pchase_gpu.hpp:686 - an application may fill the
+// block after init and change it between the solves of a sequence, examples/4_interface/4_c_dist_chase.c); V is the
+// caller's host block of local rows (m x (nev+nex), ld = m; 2*(nev+nex) columns for pseudo-Hermitian problems) — read when
+// mode == 'A', written after the solve (End() copies the eigenvectors back, pchase_gpu.hpp:1010-1018); irsrc / icsrc must
+// be 0 (the reference's distribution functions assume it too, distMatrix.hpp:44-67 numroc with isrcproc = 0).
 #include <complex>
 #include <cstdlib>
 #include <cstring>
@@ -41,6 +42,8 @@ struct DistSlot {
     std::size_t N = 0, nev = 0, nex = 0, ncol = 0, m = 0, n = 0, mb = 0, nb = 0;
     int nprow = 1, npcol = 1, myrow = 0, mycol = 0;
     void* dH = nullptr;
+    void* H = nullptr;                         // the caller's host block, re-read at every solve
+    int ldh = 0;
     void* V = nullptr;
     double* ritzv = nullptr;
     std::vector<double> own_v, own_ritzv;
@@ -48,7 +51,7 @@ struct DistSlot {
     {
         if (s) { chase_hip_solver_destroy(s); s = nullptr; }
         if (dH && ctx) { chase_hip_free(ctx, dH); }
-        dH = nullptr;
+        dH = nullptr; H = nullptr; ldh = 0;
         if (own_grid) {
             if (grid) chase_hip_grid_destroy(grid);
             if (ctx) chase_hip_ctx_destroy(ctx);
@@ -58,9 +61,12 @@ struct DistSlot {
         V = nullptr; ritzv = nullptr;
     }
 };
-DistSlot g_pd, g_pz;                           // one distributed solver per type, like the reference's static members
-chase_hip_ctx* g_next_ctx = nullptr;           // set by chase_hip_cshim_adopt for the next init
-bool g_next_own = false;
+// one distributed solver per type like the reference's static members (chase_c_interface.cpp:905-1290) - per calling
+// THREAD: a rank is a thread here when one process drives several GPUs (one thread per device), and the whole process when
+// the application is an ordinary single-threaded MPI rank, which is the reference's case
+thread_local DistSlot g_pd, g_pz;
+thread_local chase_hip_ctx* g_next_ctx = nullptr;           // set by chase_hip_cshim_use_ctx for the next init
+thread_local bool g_next_own = false;
 
 // mbsize / nbsize == 0: block layout (block length rule of the reference, distMatrix.hpp:2000-2039)
 void init_dist(DistSlot& sl, int cplx, int pseudo, int N, int nev, int nex, int mb, int nb, int m_in, int n_in, void* H,
@@ -95,8 +101,8 @@ void init_dist(DistSlot& sl, int cplx, int pseudo, int N, int nev, int nex, int 
         return;
     }
     const std::size_t es = cplx ? 16 : 8;
-    if (chase_hip_malloc(ctx, &sl.dH, sl.m * sl.n * es) ||
-        chase_hip_upload_matrix(ctx, cplx, (int)sl.m, (int)sl.n, H, ldh, sl.dH, (long)sl.m)) { sl.clear(); return; }
+    sl.H = H; sl.ldh = ldh;
+    if (chase_hip_malloc(ctx, &sl.dH, sl.m * sl.n * es)) { sl.clear(); return; }          // filled at every solve
     if (!V) {                                   // *_internal_: the interface owns the local V block and ritzv
         sl.own_v.assign(sl.m * sl.ncol * (cplx ? 2 : 1), 0.0);
         sl.own_ritzv.assign(sl.ncol, 0.0);
@@ -123,6 +129,8 @@ void solve_dist(DistSlot& sl, int deg, double tol, char mode, char opt, char qr)
     chase_hip_solver_set(sl.s, "opt", opt == 'S' ? 1.0 : 0.0);
     chase_hip_solver_set(sl.s, "approx", mode == 'A' ? 1.0 : 0.0);
     chase_hip_solver_set(sl.s, "cholqr", qr == 'C' ? 1.0 : 0.0);
+    // the matrix as the caller's block holds it NOW (Hmat_->H2D() in initVecs, pchase_gpu.hpp:686)
+    if (chase_hip_upload_matrix(sl.ctx, sl.cplx, (int)sl.m, (int)sl.n, sl.H, sl.ldh, sl.dH, (long)sl.m)) return;
     if (mode == 'A' && chase_hip_psolver_upload_v(sl.s, sl.V, sl.m)) return;       // approximate vectors from the caller
     if (chase_hip_solver_solve(sl.s, 0)) return;
     chase_hip_psolver_download_v(sl.s, sl.V, sl.m);                                 // End(): eigenvectors back to the host block
@@ -139,9 +147,16 @@ void get_pairs_dist(const DistSlot& sl, void* out, int ld, double* ritzv)
 int ham_io(DistSlot& sl, const char* filename, bool read)
 {
     if (!sl.s || !filename) return chase_hip::set_error(CHASE_HIP_EINVAL, "p?chase_{read,wrt}Ham_: no initialised solver");
-    if (read)
-        return chase_hip_load_matrix_shard(sl.ctx, filename, sl.cplx, (long)sl.N, (int)sl.m, (int)sl.n, (int)sl.mb, sl.nprow,
-                                           sl.myrow, (int)sl.nb, sl.npcol, sl.mycol, sl.dH, (long)sl.m);
+    if (read) {
+        // the reference reads into the caller's host block (readFromBinaryFile on the CPU data, distMatrix.hpp:2425-2520);
+        // here the shard goes through HBM and back so that the next solve's upload sees the loaded matrix
+        int rc = chase_hip_load_matrix_shard(sl.ctx, filename, sl.cplx, (long)sl.N, (int)sl.m, (int)sl.n, (int)sl.mb, sl.nprow,
+                                             sl.myrow, (int)sl.nb, sl.npcol, sl.mycol, sl.dH, (long)sl.m);
+        if (rc) return rc;
+        return chase_hip_download_matrix(sl.ctx, sl.cplx, (int)sl.m, (int)sl.n, sl.dH, (long)sl.m, sl.H, sl.ldh);
+    }
+    // the matrix the caller holds now (it may never have been solved with)
+    if (int rc = chase_hip_upload_matrix(sl.ctx, sl.cplx, (int)sl.m, (int)sl.n, sl.H, sl.ldh, sl.dH, (long)sl.m)) return rc;
     return chase_hip_save_matrix_shard(sl.ctx, filename, sl.cplx, (long)sl.N, (int)sl.m, (int)sl.n, (int)sl.mb, sl.nprow,
                                        sl.myrow, (int)sl.nb, sl.npcol, sl.mycol, sl.dH, (long)sl.m);
 }

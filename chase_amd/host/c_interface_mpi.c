@@ -38,8 +38,10 @@ static chase_hip_grid* make_grid(int dim0, int dim1, const char* grid_major, MPI
         MPI_Comm_split_type(comm, MPI_COMM_TYPE_SHARED, rank, MPI_INFO_NULL, &node);
         MPI_Comm_rank(node, &lrank);
         MPI_Comm_free(&node);
+        /* the devices this process can see (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES respected); a launcher that already
+         * binds one device per rank leaves exactly one, and every rank then takes device 0 */
         const char* vis = getenv("CHASE_HIP_DEVICES_PER_NODE");
-        const int ndev = vis ? atoi(vis) : 8;
+        int ndev = vis ? atoi(vis) : chase_hip_device_count();
         dev = lrank % (ndev > 0 ? ndev : 1);
     }
     int ok = chase_hip_ctx_create(ctx, dev, NULL) == 0, all_ok = 0;
@@ -163,4 +165,91 @@ void pzchase_init_pseudo_blockcyclic_internal_(int* N, int* nev, int* nex, int* 
 {
     GRID_OR_FAIL;
     pzchase_init_pseudo_blockcyclic_internal_hip_(N, nev, nex, mbsize, nbsize, H, ldh, irsrc, icsrc, g, init);
+}
+
+/* ---- Fortran communicators: the reference's *_f_ twins (interface/chase_c_interface.cpp:2425-3030) take an MPI_Fint handle,
+ * convert it with MPI_Comm_f2c and do the same ---- */
+void pdchase_init_f_(int* N, int* nev, int* nex, int* m, int* n, double* H, int* ldh, double* V, double* ritzv, int*
+                     dim0, int* dim1, char* grid_major, MPI_Fint* fcomm, int* init)
+{
+    MPI_Comm comm = MPI_Comm_f2c(*fcomm);
+    pdchase_init_(N, nev, nex, m, n, H, ldh, V, ritzv, dim0, dim1, grid_major, &comm, init);
+}
+void pdchase_init_internal_f_(int* N, int* nev, int* nex, int* m, int* n, double* H, int* ldh, int* dim0, int* dim1,
+                              char* grid_major, MPI_Fint* fcomm, int* init)
+{
+    MPI_Comm comm = MPI_Comm_f2c(*fcomm);
+    pdchase_init_internal_(N, nev, nex, m, n, H, ldh, dim0, dim1, grid_major, &comm, init);
+}
+void pzchase_init_f_(int* N, int* nev, int* nex, int* m, int* n, double _Complex* H, int* ldh, double _Complex* V,
+                     double* ritzv, int* dim0, int* dim1, char* grid_major, MPI_Fint* fcomm, int* init)
+{
+    MPI_Comm comm = MPI_Comm_f2c(*fcomm);
+    pzchase_init_(N, nev, nex, m, n, H, ldh, V, ritzv, dim0, dim1, grid_major, &comm, init);
+}
+void pzchase_init_internal_f_(int* N, int* nev, int* nex, int* m, int* n, double _Complex* H, int* ldh, int* dim0,
+                              int* dim1, char* grid_major, MPI_Fint* fcomm, int* init)
+{
+    MPI_Comm comm = MPI_Comm_f2c(*fcomm);
+    pzchase_init_internal_(N, nev, nex, m, n, H, ldh, dim0, dim1, grid_major, &comm, init);
+}
+void pzchase_init_pseudo_f_(int* N, int* nev, int* nex, int* m, int* n, double _Complex* H, int* ldh, double _Complex*
+                            V, double* ritzv, int* dim0, int* dim1, char* grid_major, MPI_Fint* fcomm, int* init)
+{
+    MPI_Comm comm = MPI_Comm_f2c(*fcomm);
+    pzchase_init_pseudo_(N, nev, nex, m, n, H, ldh, V, ritzv, dim0, dim1, grid_major, &comm, init);
+}
+void pzchase_init_pseudo_internal_f_(int* N, int* nev, int* nex, int* m, int* n, double _Complex* H, int* ldh, int*
+                                     dim0, int* dim1, char* grid_major, MPI_Fint* fcomm, int* init)
+{
+    MPI_Comm comm = MPI_Comm_f2c(*fcomm);
+    pzchase_init_pseudo_internal_(N, nev, nex, m, n, H, ldh, dim0, dim1, grid_major, &comm, init);
+}
+void pdchase_init_blockcyclic_f_(int* N, int* nev, int* nex, int* mbsize, int* nbsize, double* H, int* ldh, double* V,
+                                 double* ritzv, int* dim0, int* dim1, char* grid_major, int* irsrc, int* icsrc,
+                                 MPI_Fint* fcomm, int* init)
+{
+    MPI_Comm comm = MPI_Comm_f2c(*fcomm);
+    pdchase_init_blockcyclic_(N, nev, nex, mbsize, nbsize, H, ldh, V, ritzv, dim0, dim1, grid_major, irsrc, icsrc,
+        &comm, init);
+}
+void pdchase_init_blockcyclic_internal_f_(int* N, int* nev, int* nex, int* mbsize, int* nbsize, double* H, int* ldh,
+                                          int* dim0, int* dim1, char* grid_major, int* irsrc, int* icsrc, MPI_Fint*
+                                          fcomm, int* init)
+{
+    MPI_Comm comm = MPI_Comm_f2c(*fcomm);
+    pdchase_init_blockcyclic_internal_(N, nev, nex, mbsize, nbsize, H, ldh, dim0, dim1, grid_major, irsrc, icsrc,
+        &comm, init);
+}
+void pzchase_init_blockcyclic_f_(int* N, int* nev, int* nex, int* mbsize, int* nbsize, double _Complex* H, int* ldh,
+                                 double _Complex* V, double* ritzv, int* dim0, int* dim1, char* grid_major, int*
+                                 irsrc, int* icsrc, MPI_Fint* fcomm, int* init)
+{
+    MPI_Comm comm = MPI_Comm_f2c(*fcomm);
+    pzchase_init_blockcyclic_(N, nev, nex, mbsize, nbsize, H, ldh, V, ritzv, dim0, dim1, grid_major, irsrc, icsrc,
+        &comm, init);
+}
+void pzchase_init_blockcyclic_internal_f_(int* N, int* nev, int* nex, int* mbsize, int* nbsize, double _Complex* H,
+                                          int* ldh, int* dim0, int* dim1, char* grid_major, int* irsrc, int* icsrc,
+                                          MPI_Fint* fcomm, int* init)
+{
+    MPI_Comm comm = MPI_Comm_f2c(*fcomm);
+    pzchase_init_blockcyclic_internal_(N, nev, nex, mbsize, nbsize, H, ldh, dim0, dim1, grid_major, irsrc, icsrc,
+        &comm, init);
+}
+void pzchase_init_pseudo_blockcyclic_f_(int* N, int* nev, int* nex, int* mbsize, int* nbsize, double _Complex* H, int*
+                                        ldh, double _Complex* V, double* ritzv, int* dim0, int* dim1, char*
+                                        grid_major, int* irsrc, int* icsrc, MPI_Fint* fcomm, int* init)
+{
+    MPI_Comm comm = MPI_Comm_f2c(*fcomm);
+    pzchase_init_pseudo_blockcyclic_(N, nev, nex, mbsize, nbsize, H, ldh, V, ritzv, dim0, dim1, grid_major, irsrc,
+        icsrc, &comm, init);
+}
+void pzchase_init_pseudo_blockcyclic_internal_f_(int* N, int* nev, int* nex, int* mbsize, int* nbsize, double
+                                                 _Complex* H, int* ldh, int* dim0, int* dim1, char* grid_major, int*
+                                                 irsrc, int* icsrc, MPI_Fint* fcomm, int* init)
+{
+    MPI_Comm comm = MPI_Comm_f2c(*fcomm);
+    pzchase_init_pseudo_blockcyclic_internal_(N, nev, nex, mbsize, nbsize, H, ldh, dim0, dim1, grid_major, irsrc,
+        icsrc, &comm, init);
 }

@@ -511,7 +511,13 @@ protected:
         // the panel products run beside the previous panel's all-reduce: finer work units, so that the CUs the collective
         // takes displace a fraction of a tile (chase_hip_ctx_set_gemm_min_rounds; CHASE_HIP_PANEL_ROUNDS, 0 = off)
         static const int panel_rounds = [] { const char* e = std::getenv("CHASE_HIP_PANEL_ROUNDS"); return e ? std::atoi(e) : 4; }();
-        if (pipe) hip_ok(chase_hip_ctx_set_gemm_min_rounds(ctx_, panel_rounds), "gemm_min_rounds");
+        // restored on every way out: hip_ok / coll throw, and a context left in forced K-split mode would give every later
+        // product another decomposition (and rounding)
+        struct RoundsGuard {
+            chase_hip_ctx* ctx;
+            RoundsGuard(chase_hip_ctx* c, int r) : ctx(c) { if (c) chase_hip_ctx_set_gemm_min_rounds(c, r); }
+            ~RoundsGuard() { if (ctx) chase_hip_ctx_set_gemm_min_rounds(ctx, 0); }
+        } rounds_guard(pipe ? ctx_ : nullptr, panel_rounds);
         std::size_t c = c0;
         while (c < c0 + nc) {
             const std::size_t fp = c / panel_;                                 // fixed panel index
@@ -524,7 +530,6 @@ protected:
             if (pipe) coll(chase_hip_grid_event_record(grid_, (int)fp));
             c = cend;
         }
-        if (pipe) hip_ok(chase_hip_ctx_set_gemm_min_rounds(ctx_, 0), "gemm_min_rounds");
     }
     // X <- S X on the local rows of a column-type / row-type block (global rows >= N/2 change sign)
     void flip_coltype(T* X, std::size_t ncols, double s = -1.0)

@@ -45,6 +45,8 @@ const char* chase_hip_last_error(void);
 int chase_hip_device_info(chase_hip_ctx* ctx, int* num_cu, int* clock_khz, size_t* hbm_bytes, char* name,
                           int name_len);
 const char* chase_hip_version(void);
+/* HIP devices visible to this process (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES applied); 0 without a GPU */
+int chase_hip_device_count(void);
 
 /* ---- device memory plumbing ----------------------------------------------------------------------------------- */
 int chase_hip_malloc(chase_hip_ctx* ctx, void** dev, size_t bytes);

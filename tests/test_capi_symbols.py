@@ -37,6 +37,7 @@ def test_mpi_front_end_exports_the_reference_signatures():
               "pdchase_init_blockcyclic_", "pdchase_init_blockcyclic_internal_", "pzchase_init_blockcyclic_",
               "pzchase_init_blockcyclic_internal_", "pzchase_init_pseudo_blockcyclic_"):
         assert f" T {n}\n" in out, n
+        assert f" T {n[:-1]}_f_\n" in out, n + " (MPI_Fint twin, chase_c_interface.cpp:2425-3030)"
 
 
 def test_fails_loudly_without_gpu_or_runs_on_one():

@@ -1,0 +1,108 @@
+"""The few GPU tests that need ranks as PROCESSES; run after every in-process file (tests/conftest.py orders the files) so that a process-count problem on the box can
+never hide the in-process suite again.  Never more than 4 worker processes + this pytest process hold the GPU (box limit: 6).
+* the RCCL transport through size-1 communicators in a fresh process (ncclCommInitRank / ncclAllReduce / ncclBroadcast, the
+  communication stream and per-panel events);
+* one 4-process host-transport run (the torch.distributed/gloo fabric bench.py's launcher and dist_bench use);
+* the reference's MPI_Comm* entry points (libchase_hip_mpi.so) on one MPI rank, and the plain-C MPI example."""
+import os
+import subprocess
+import sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_PORT = [29611]
+
+
+def run_ranks(nranks, transport, *args, timeout=600, env_extra=None):
+    assert nranks <= 4, "box limit: at most 6 processes with the GPU open, pytest itself is one of them"
+    _PORT[0] += 1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_PORT[0]),
+           os.path.join(ROOT, "tests", "dist_worker.py"), transport, *map(str, args)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", **(env_extra or {}))
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert p.returncode == 0 and "DIST_WORKER_OK" in p.stdout, (p.stdout[-3000:], p.stderr[-3000:])
+
+
+def test_solve_rccl_transport_single_rank():
+    run_ranks(1, "rccl", "solve", 256, 24, 16, "z", 0, 16)
+
+
+def test_rccl_forced_through_size1_communicators():
+    """CHASE_HIP_RCCL_FORCE routes the size-1 row/column groups through real RCCL communicators: ncclCommInitRank,
+    ncclAllReduce, ncclBroadcast, the communication stream, the per-panel events of the pipelined HEMM (Hermitian and
+    pseudo-Hermitian filter)."""
+    force = {"CHASE_HIP_RCCL_FORCE": "1"}
+    run_ranks(1, "rccl", "solve", 1001, 100, 60, "z", 64, 20, env_extra=force)
+    run_ranks(1, "rccl", "ops", "d", 0, env_extra=force)
+    run_ranks(1, "rccl", "pseudo_solve", 0, env_extra=force)
+    run_ranks(1, "rccl", "pseudo_ops", 0, env_extra=force)
+
+
+def test_four_processes_share_the_gpu_through_gloo():
+    """ranks as processes on the torch.distributed (gloo) fabric: 2 x 2 block-cyclic operators + the C entry points"""
+    run_ranks(4, "host", "ops", "z", 16)
+    run_ranks(4, "host", "cshim", "d", 0)
+
+
+def test_reference_mpi_signatures_on_one_rank():
+    """libchase_hip_mpi.so: the reference's exact MPI_Comm* entry points (pzchase_init_blockcyclic_ ..., built when mpi.h is
+    found).  One MPI rank (singleton MPI_Init, no launcher) on a 1 x 1 grid: communicator split, id broadcast, grid and
+    context creation, solve, finalize releasing both."""
+    mpi_lib = os.path.join(ROOT, "chase_amd", "lib", "libchase_hip_mpi.so")
+    if not os.path.exists(mpi_lib) or not os.path.exists("/opt/conda/lib/libmpi.so.12"):
+        pytest.skip("MPI front end not built (no mpi.h / libmpi on this box)")
+    code = """
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r)
+from chase_amd.capi import lib
+from oracle import chase_oracle as O
+mpi = C.CDLL("/opt/conda/lib/libmpi.so.12", mode=C.RTLD_GLOBAL)
+assert mpi.MPI_Init(None, None) == 0
+front = C.CDLL(%r)
+world = C.c_int(0x44000000)                      # MPICH's MPI_COMM_WORLD handle
+N, nev, nex, nb = 300, 24, 16, 32
+H = O.clement(N, True)
+V = np.zeros((N, nev + nex), dtype=complex, order="F"); ritzv = np.zeros(nev + nex)
+I = lambda v: C.byref(C.c_int(v))
+init = C.c_int(0)
+front.pzchase_init_blockcyclic_(I(N), I(nev), I(nex), I(nb), I(nb), C.c_void_p(H.ctypes.data), I(N), C.c_void_p(V.ctypes.data),
+                                C.c_void_p(ritzv.ctypes.data), I(1), I(1), C.c_char_p(b"C"), I(0), I(0), C.byref(world), C.byref(init))
+assert init.value == 1, lib.chase_hip_last_error()
+deg, tol = C.c_int(20), C.c_double(1e-10)
+lib.pzchase_(C.byref(deg), C.byref(tol), C.c_char_p(b"R"), C.c_char_p(b"S"), C.c_char_p(b"C"))
+k = O.OracleCPU(H, nev, nex); O.solve(k)
+assert np.max(np.abs(ritzv[:nev] - k.ritzv[:nev])) < 1e-8
+assert np.max(O.residuals(H, ritzv[:nev], V[:, :nev])) < 1e-8
+flag = C.c_int(5); lib.pzchase_finalize_(C.byref(flag)); assert flag.value == 0
+# the block-layout entry point rejects a local shape that does not match the layout
+front.pzchase_init_(I(N), I(nev), I(nex), I(N - 1), I(N), C.c_void_p(H.ctypes.data), I(N), C.c_void_p(V.ctypes.data),
+                    C.c_void_p(ritzv.ctypes.data), I(1), I(1), C.c_char_p(b"R"), C.byref(world), C.byref(init))
+assert init.value == 0
+mpi.MPI_Finalize()
+print("MPI_FRONT_OK")
+""" % (ROOT, mpi_lib)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0 and "MPI_FRONT_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
+def test_c_mpi_application_example(tmp_path):
+    """examples/c_dist_mpi.c: an MPI program in plain C on the reference's distributed entry points (pzchase_init_, pzchase_,
+    pzchase_finalize_), built with gcc against libchase_hip_mpi.so + libchase_hip.so and run as one MPI rank (one GPU here)."""
+    import shutil
+    mpi_inc, mpi_lib = "/opt/conda/include", "/opt/conda/lib"
+    lib = os.path.join(ROOT, "chase_amd", "lib")
+    if not (os.path.exists(os.path.join(lib, "libchase_hip_mpi.so")) and os.path.exists(os.path.join(mpi_inc, "mpi.h"))
+            and shutil.which("gcc")):
+        pytest.skip("no MPI / gcc on this box")
+    exe = str(tmp_path / "c_dist_mpi")
+    subprocess.run(["gcc", "-O2", "-std=gnu11", "-I" + os.path.join(ROOT, "include"), "-I" + mpi_inc,
+                    os.path.join(ROOT, "examples", "c_dist_mpi.c"), "-L" + lib, "-lchase_hip_mpi", "-lchase_hip",
+                    os.path.join(mpi_lib, "libmpi.so"), "-Wl,--allow-shlib-undefined", "-Wl,--enable-new-dtags",
+                    "-Wl,-rpath," + lib, "-Wl,-rpath," + mpi_lib, "-lm", "-o", exe],
+                   check=True)
+    p = subprocess.run([exe, "600"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0 and "-> OK" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
