@@ -72,39 +72,92 @@ def spectrum_check(lam, N, nev):
     return {"max_abs_dev_from_analytic": dev, "bound": tol, "ok": bool(dev <= tol)}
 
 
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, cut by a cgroup CPU quota if there is one (a GPU box
+    hands a job a share of its cores; os.cpu_count() reports the machine)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            n = min(n, max(1, int(q / per + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(N, cplx, ncols, budget_s=25.0):
-    """Times the CPU oracle's filter HEMM (oracle/chase_oracle.py: OracleCPU.HEMM -> numpy/OpenBLAS gemm) on a bounded
-    sample of the same workload: as many rows of H as the host comfortably holds, 128 columns."""
+    """The CPU path beside the GPU number: the oracle's operators (oracle/chase_oracle.py - numpy on the
+    host BLAS / LAPACK, the restatement of Impl/chase_cpu's HEMM = one t_gemm per call, chase_cpu.hpp:449-508) on a BOUNDED
+    sample of the workload: a 16384 x 16384 slice of the operator times 1024 columns (2.2e12 flops per complex HEMM call),
+    a few full HEMM steps and ONE QR / Rayleigh-Ritz / residual pass at that slice.  `value` is the HEMM rate of the sample;
+    the full-size figure is an extrapolation from it and is labelled so."""
     from oracle import chase_oracle as O
-    threads = os.cpu_count() or 1
+    cores = usable_cores()
+    blas = "numpy BLAS"
+    limiter = None
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+        limiter = threadpool_limits(limits=cores)           # as many BLAS threads as cores we may use, not as the box has
+        info = [i for i in threadpool_info() if i.get("user_api") == "blas"]
+        if info:
+            blas = "%s %s (%s threads)" % (info[0].get("internal_api"), info[0].get("version"), info[0].get("num_threads"))
+    except Exception:
+        pass
     F = 4 if cplx else 1
-    # bound the sample: H is N x N (the oracle needs it on the host); shrink N if the host cannot hold it comfortably
     n_s = N
-    while n_s * n_s * (16 if cplx else 8) > 6e9:
+    while n_s * n_s * (16 if cplx else 8) > 6e9:             # the oracle needs its operator on the host: bound the slice
         n_s //= 2
-    cols = min(ncols, 128)
+    cols = min(ncols, 1024)
     H = O.clement(n_s, cplx, perturb=0)
     k = O.OracleCPU(H, cols // 2, cols - cols // 2)
+    del H
     rng = np.random.default_rng(0)
     k.V1[:] = rng.standard_normal(k.V1.shape)
+    if cplx:
+        k.V1.imag[:] = rng.standard_normal(k.V1.shape)
     k.V2[:] = k.V1
     t0 = time.perf_counter()
     k.HEMM(cols, 0.01, 0.0, 0)                       # warm-up / thread pool start
     t_first = time.perf_counter() - t0
-    reps = int(max(1, min(20, (budget_s - t_first) / max(t_first, 1e-3))))
+    hemm_budget = 0.5 * budget_s
+    reps = int(max(1, min(10, (hemm_budget - t_first) / max(t_first, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(reps):
         k.HEMM(cols, 0.01, -0.5, 0)
     dt = (time.perf_counter() - t0) / reps
     gflops = 2.0 * F * n_s * n_s * cols / dt / 1e9
-    out = {"value": gflops, "unit": "GFLOP/s", "cores": threads, "kind": "port",
-           "sample": ("oracle filter HEMM (numpy/OpenBLAS %s) on a %d x %d slice of the workload's operator times 128 of "
-                      "its %d columns, %d repetitions; a GEMM rate does not depend on the sample size, so this IS the "
-                      "rate the CPU path would sustain on the full N = %d workload (extrapolated from the sample, not "
-                      "measured at full size)") % ("zgemm" if cplx else "dgemm", n_s, n_s, ncols, reps, N),
-           "sample_shape": {"N": n_s, "ncols": cols, "reps": reps, "seconds_per_call": dt}}
+    out = {"value": gflops, "unit": "GFLOP/s", "cores": cores, "kind": "port",
+           "blas": blas,
+           "sample": ("oracle filter HEMM (%s, %s, %d threads on the %d host cores this job may use; the machine reports "
+                      "%d) on a %d x %d slice of the workload's operator times %d of its %d columns, %d full steps; the "
+                      "rate for the full N = %d workload is extrapolated from this sample, not measured at full size")
+                     % ("zgemm" if cplx else "dgemm", blas, cores, cores, os.cpu_count() or 0, n_s, n_s, cols, ncols, reps, N),
+           "sample_shape": {"N": n_s, "ncols": cols, "reps": reps, "seconds_per_call": dt,
+                            "flop_per_call": 2.0 * F * n_s * n_s * cols}}
+    # one QR / Rayleigh-Ritz / residual pass of the oracle at the same slice (BASELINE.md 3.4)
+    try:
+        k.V1[:] = rng.standard_normal(k.V1.shape)
+        k.V2[:] = k.V1
+        k.Start()
+        ops = {}
+        t0 = time.perf_counter(); k.QR(0, 1.0); ops["qr_seconds"] = time.perf_counter() - t0
+        t0 = time.perf_counter(); k.RR(k.ritzv, cols); ops["rr_seconds"] = time.perf_counter() - t0
+        t0 = time.perf_counter(); k.Resd(k.ritzv, k.resid, 0); ops["resd_seconds"] = time.perf_counter() - t0
+        ops["qr_variant"] = k.qr_variant
+        out["operator_pass"] = ops
+    except Exception as e:
+        out["operator_pass"] = {"error": str(e)}
+    del k
     # second bounded sample: one complete oracle solve of the reference's CPU-runnable configuration (BASELINE configs[0]:
-    # N = 4096 real, nev = 100, nex = 40; the reference itself measured 5.44 s on 8 vCPU, SURVEY.md §6)
+    # N = 4096 real, nev = 100, nex = 40; the reference itself measured 5.44 s on 8 vCPU, SURVEY.md 6)
     try:
         t0 = time.perf_counter()
         Hs = O.clement(4096, False, perturb=0)
@@ -116,6 +169,8 @@ def cpu_baseline(N, cplx, ncols, budget_s=25.0):
                                "filtered_vecs": so["filtered_vecs"]}
     except Exception as e:  # the HEMM sample above is the contract; this one is informative
         out["solve_sample"] = {"error": str(e)}
+    if limiter is not None:
+        limiter.restore_original_limits()
     return out
 
 
@@ -165,8 +220,10 @@ class StepTimer:
             if self.boundary == self.warmup + self.steps:
                 self.t1, self.c1 = self._bracket()
         self.start_if_due()
-        # once the timed iterations are in and a complete solve exists for the parity guard, stop iterating
-        return self.done and self.complete_solves >= 1
+        # never cut a solve short: the solve in flight when the timed region ends runs to completion (its remaining
+        # iterations are the cheap ones), so that the LAST solve is always a complete one and the independent residual
+        # check after the timed region sees that solve's eigenvectors on the device
+        return False
 
     def diff(self, key):
         return self.c1[key] - self.c0[key]
@@ -299,7 +356,11 @@ def run_single(args):
     gflops = model_flops / filt_s / 1e9
     lam, resid = last
     spec = spectrum_check(lam, N, nev)
-    ok = bool(np.all(np.isfinite(lam)) and np.max(resid) < 1e-8 and spec["ok"])
+    # independent check outside the timed region (the reference's solve tests: tests/chase_serial_solve.cpp:144-148,195-199):
+    # one fresh four-product H V over the nev eigenvectors of the last solve + the residual-norm kernel.  The solver's own
+    # residuals come from (H Q) A left behind by Rayleigh-Ritz, these from H itself.
+    resid_re = s.recompute_residuals(nev, lam)
+    ok = bool(np.all(np.isfinite(lam)) and np.max(resid) < 1e-8 and np.max(resid_re) < 1e-8 and spec["ok"])
     st = complete[-1]
     solve_s = float(np.mean([c["t_all"] for c in complete]))
     out = {
@@ -313,7 +374,8 @@ def run_single(args):
                    "N": N, "nev": nev, "nex": nex, "grid": "1x1", "step": "outer iteration"},
         "eigenpairs_per_sec": nev / solve_s, "solve_seconds": solve_s, "complete_solves": len(complete),
         "pct_fp64_mfma_peak": 100.0 * exec_flops / filt_s / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-        "converged": ok, "max_resid": float(np.max(resid)), "spectrum_check": spec,
+        "converged": ok, "max_resid": float(np.max(resid)), "max_resid_recomputed": float(np.max(resid_re)),
+        "spectrum_check": spec,
         "iterations_per_solve": st["iterations"], "filtered_vecs_per_solve": st["filtered_vecs"],
         "timed": {"filtered_vecs": timer.filtered_timed, "hemm_vecs": hemm_vecs, "first_step_vecs_from_rr": reused,
                   "filter_seconds_device": filt_s, "wall_seconds": wall,
@@ -336,6 +398,54 @@ def run_single(args):
     return out
 
 
+def kfd_gpu_count():
+    """GPUs of this node from the driver's topology files - without initialising any GPU runtime in this process."""
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for d in os.listdir(base):
+            try:
+                props = dict(l.split()[:2] for l in open(os.path.join(base, d, "properties")) if len(l.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        return 0
+    return n
+
+
+def bind_one_device(env, local_rank):
+    """One process per GPU means one GPU per process: restrict the ROCm runtime of a rank to its own device BEFORE the rank
+    touches HIP, so that no rank holds the other ranks' devices open (the reference picks device = node-local rank,
+    grid/mpiGrid2D.hpp:225-233; the pool's boxes allow only a few processes per card).  ROCR_VISIBLE_DEVICES is what keeps
+    the runtime from opening a device at all (HIP_VISIBLE_DEVICES only hides it from the HIP API); RCCL finds its xGMI peers
+    through the driver topology, not through visibility.  An existing visibility list is honoured: the rank takes ITS entry.
+    CHASE_HIP_BIND=0 restores full visibility (every rank then selects device local_rank itself).  Edits `env` in place and
+    returns the physical index (or None when binding is off)."""
+    if env.get("CHASE_HIP_BIND", "1") == "0" or env.get("CHASE_HIP_TRANSPORT") == "host":
+        return None                                       # (the host test transport lets ranks SHARE a device)
+    def ids(name):
+        v = env.get(name, "").strip()
+        return [x.strip() for x in v.split(",") if x.strip()] if v else None
+    rocr = ids("ROCR_VISIBLE_DEVICES")
+    hipv = ids("HIP_VISIBLE_DEVICES") or ids("CUDA_VISIBLE_DEVICES")
+    pick = str(local_rank)
+    if hipv is not None:                                  # HIP's list indexes into the runtime's list
+        pick = hipv[local_rank % len(hipv)]
+    if rocr is not None:
+        pick = rocr[int(pick) % len(rocr)] if pick.isdigit() else pick
+    elif pick.isdigit():
+        ngpu = kfd_gpu_count()
+        if ngpu and int(pick) >= ngpu:                    # more ranks than devices: wrap like device = local_rank % ndev
+            pick = str(int(pick) % ngpu)
+    env["ROCR_VISIBLE_DEVICES"] = pick
+    env.pop("HIP_VISIBLE_DEVICES", None)
+    env.pop("CUDA_VISIBLE_DEVICES", None)
+    env["CHASE_HIP_BOUND_DEVICE"] = pick                  # for the rank's report line; device ordinal inside the rank is 0
+    return pick
+
+
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` (N > 1) without a launcher: start N ranks of this script as child processes — one per
     GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set like torch.distributed.run does (the reference bootstraps its own
@@ -352,6 +462,7 @@ def spawn_ranks(args, argv):
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        bind_one_device(env, r)
         f = tempfile.TemporaryFile(mode="w+") if r == 0 else None
         outs.append(f)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
@@ -414,6 +525,11 @@ def main():
         # BEFORE anything initialises HIP / torch in this process
         sys.exit(spawn_ranks(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    if launched and world > 1 and "CHASE_HIP_BOUND_DEVICE" not in os.environ:
+        # started by torch.distributed.run (the driver's multi-GPU call): nothing in this process has touched HIP yet
+        # (numpy only), so the binding can still be made here, in place
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        bind_one_device(os.environ, int(os.environ.get("LOCAL_RANK", os.environ["RANK"])))
     if world > 1 or args.dist or args.workload in PSEUDO_WORKLOADS:
         if not launched:
             # grid Impl on a 1x1 grid (communicator-free) when started directly on one GPU

@@ -51,6 +51,8 @@ _sig("chase_hip_ctx_destroy", c_int, c_void_p)
 _sig("chase_hip_ctx_sync", c_int, c_void_p)
 _sig("chase_hip_ctx_stream", c_void_p, c_void_p)
 _sig("chase_hip_device_info", c_int, c_void_p, P(c_int), P(c_int), P(c_size_t), C.c_char_p, c_int)
+_sig("chase_hip_device_bus_id", c_int, c_void_p, C.c_char_p, c_int)
+_sig("chase_hip_device_count", c_int)
 _sig("chase_hip_malloc", c_int, c_void_p, P(c_void_p), c_size_t)
 _sig("chase_hip_free", c_int, c_void_p, c_void_p)
 _sig("chase_hip_memcpy_h2d", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
@@ -146,6 +148,11 @@ class Context:
         name = C.create_string_buffer(128)
         check(lib.chase_hip_device_info(self.h, C.byref(ncu), C.byref(clk), C.byref(mem), name, 128), "device_info")
         return {"num_cu": ncu.value, "clock_khz": clk.value, "hbm_bytes": mem.value, "name": name.value.decode()}
+
+    def bus_id(self):
+        b = C.create_string_buffer(64)
+        check(lib.chase_hip_device_bus_id(self.h, b, 64), "device_bus_id")
+        return b.value.decode()
 
     def empty(self, shape, dtype):
         return DeviceArray(self, shape, dtype)
@@ -283,6 +290,7 @@ _sig("chase_hip_ctx_gemm_counters", c_int, c_void_p, c_int, P(c_double), P(c_dou
 _sig("chase_hip_solver_stats", c_int, c_void_p, P(Stats))
 _sig("chase_hip_solver_resid", P(c_double), c_void_p)
 _sig("chase_hip_solver_trace", C.c_char_p, c_void_p)
+_sig("chase_hip_solver_recompute_residuals", c_int, c_void_p, c_size_t, c_void_p, c_void_p)
 _sig("chase_hip_solver_peek_v", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
 _sig("chase_hip_op_start", c_int, c_void_p)
 _sig("chase_hip_op_end", c_int, c_void_p)
@@ -313,6 +321,14 @@ def set_iteration_hook(solver, fn):
                 return 1
         solver._iter_cb = ITER_FN(_cb)                 # keep the thunk alive
     check(lib.chase_hip_solver_set_iteration_hook(solver.h, solver._iter_cb, None), "set_iteration_hook")
+
+
+def recompute_residuals(solver, ncols, lam=None):
+    """|| H v_j - lambda_j v_j || for the first ncols vectors of a solver object, from a fresh four-product H V."""
+    lam = np.ascontiguousarray(solver.ritzv[:ncols] if lam is None else lam, dtype=np.float64)
+    out = np.zeros(ncols)
+    check(lib.chase_hip_solver_recompute_residuals(solver.h, ncols, lam.ctypes.data, out.ctypes.data), "recompute_residuals")
+    return out
 
 
 def gemm_counters(ctx, phase, reset=False):
@@ -381,6 +397,9 @@ class Solver:
 
     def trace(self):
         return lib.chase_hip_solver_trace(self.h).decode().splitlines()
+
+    def recompute_residuals(self, ncols, lam=None):
+        return recompute_residuals(self, ncols, lam)
 
     def peek_v(self):
         out = np.empty_like(self.V, order="F")

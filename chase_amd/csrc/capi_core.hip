@@ -103,6 +103,13 @@ int chase_hip_ctx_sync(chase_hip_ctx* c)
 
 void* chase_hip_ctx_stream(chase_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
+int chase_hip_device_bus_id(chase_hip_ctx* c, char* out, int len)
+{
+    if (!c || !out || len < 16) return set_error(CHASE_HIP_EINVAL, "device_bus_id: bad argument");
+    HIPCHK(hipDeviceGetPCIBusId(out, len, c->device));
+    return 0;
+}
+
 int chase_hip_device_info(chase_hip_ctx* c, int* num_cu, int* clock_khz, size_t* hbm_bytes, char* name, int name_len)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "ctx == NULL");

@@ -55,16 +55,21 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef d2_t d2u_t __attribute__((aligned(8)));   // 16-byte vector that may sit on an 8-byte boundary in HBM
 
-template <bool CPLX, bool OPA_C>
+// NARROW (real only): a 128 x 64 block tile instead of 128 x 128.  Its stage is 24 KB like the complex kernels', so three
+// stages fit twice into a CU's 160 KB of LDS and the K loop is software-pipelined the same way (two tiles in flight, fragments
+// double-buffered next to 64 accumulator registers).  It serves the widths the 128-wide tile handles badly: blocks narrower
+// than a tile and the ragged rest of a width - launches that are bound by how fast H streams in, not by the matrix cores.
+template <bool CPLX, bool OPA_C, bool NARROW = false>
 struct Cfg {
+    static_assert(!(CPLX && NARROW), "the complex tile is 64 columns wide already");
     static constexpr int NTHREADS = 256;
     // the 4 waves are stacked along M and every wave spans the tile's whole width, so the 16-column groups a
     // ragged last column tile does not need are skipped by all four waves alike (balanced over the 4 SIMDs)
     static constexpr int WAVES_M = 4, WAVES_N = 1;
     static constexpr int TM = 2;                    // 16-row MFMA tiles per wave along M
-    static constexpr int TN = CPLX ? 4 : 8;         // 16-col MFMA tiles per wave along N
+    static constexpr int TN = (CPLX || NARROW) ? 4 : 8;   // 16-col MFMA tiles per wave along N
     static constexpr int BM = 16 * TM * WAVES_M;    // 128
-    static constexpr int BN = 16 * TN * WAVES_N;    // 128 (real) / 64 (complex)
+    static constexpr int BN = 16 * TN * WAVES_N;    // 128 (real) / 64 (complex, narrow real)
     static constexpr int BK = CPLX ? 8 : 16;        // elements of T along K per stage
     static constexpr int KPU = CPLX ? 1 : 2;        // k per 16-byte unit of a K-contiguous operand
     static constexpr int RPU = CPLX ? 1 : 2;        // rows per 16-byte unit of an M-contiguous operand
@@ -76,7 +81,8 @@ struct Cfg {
     static constexpr int EPT = CPLX ? 2 : 1;        // doubles per element
     // complex: 3 LDS stages filled by global_load_lds two K steps ahead (72 KB per workgroup, two workgroups per CU);
     // real: 2 stages through registers (3 x 32 KB x 2 workgroups would not fit the 160 KB LDS)
-    static constexpr int STAGES = CPLX ? 3 : 2;
+    static constexpr int STAGES = (CPLX || NARROW) ? 3 : 2;
+    static constexpr bool PIPELINED = CPLX || NARROW;   // fragments double-buffered, barrier between the two MFMA clusters
     static constexpr int A_GLDS = A_UNITS / 64, B_GLDS = B_UNITS / 64;     // wave instructions per tile
     static constexpr int GLDS_PER_WAVE = (A_GLDS + B_GLDS) / 4;
 };
@@ -139,11 +145,11 @@ struct GemmArgs {
 //   op=C (conj(A)): re = P1 + P2, im = P3 - P1 + P2  with (ar - ai).
 // 25 % fewer MFMAs for the same product; normwise backward stable like the 4-product form (the imaginary part carries the
 // absolute error of the real part), used for the Chebyshev-filter products only.
-template <bool CPLX, bool OPA_C, int TAG, bool RAGGED, bool M3>
+template <bool CPLX, bool OPA_C, int TAG, bool RAGGED, bool M3, bool NARROW = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
 {
     static_assert(CPLX || !M3, "3M applies to complex products");
-    using C_ = Cfg<CPLX, OPA_C>;
+    using C_ = Cfg<CPLX, OPA_C, NARROW>;
     constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TM = C_::TM, TN = C_::TN;
     constexpr int EPT = C_::EPT, KPU = C_::KPU, RPU = C_::RPU;
     constexpr int UM = BM / RPU;                    // units per k-column of an M-contiguous A tile
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
 
     // whole K step from one LDS stage (register-staged fallback path)
     auto compute = [&](int stage, auto&& hook) __attribute__((always_inline)) {
-        if constexpr (CPLX && !M3) {
+        if constexpr (C_::PIPELINED && !M3) {
             Frag f0, f1;
             read_chunk(stage, 0, f0);
             read_chunk(stage, 1, f1);
@@ -474,8 +480,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                 for (int u = 0; u < NA + NB; ++u) issue_one(u, st_issue);
                 st_issue = (st_issue + 1 == C_::STAGES) ? 0 : st_issue + 1;
             };
-            if constexpr (CPLX && !M3) {
-                // Software pipeline: all STAGES tiles are requested up front; each K step multiplies chunk 0 from registers
+            if constexpr (C_::PIPELINED && !M3) {
+                // Software pipeline (complex four-product kernel and the narrow real kernel): all STAGES tiles are requested up front; each K step multiplies chunk 0 from registers
                 // while chunk 1's fragments stream in from LDS, and the barrier that publishes tile kt+1 sits BETWEEN the two
                 // MFMA clusters, so chunk 0 of tile kt+1 is fetched under chunk 1's MFMAs and the stage of tile kt is refilled
                 // (tile kt+STAGES) as soon as its last fragment has been read: no MFMA ever waits for an LDS read.
@@ -856,10 +862,10 @@ constexpr int MAX_DEVICES = 64;
 // summation order, never depends on how far a caller's workspace happens to have grown.  The one place both the launcher
 // (launch_gemm_part) and the workspace sizing (gemm_f64_ws_need) take it from.
 struct PartPlan { long full, tail; int sk; size_t ws_bytes; };
-template <bool CPLX, bool OPA_C>
+template <bool CPLX, bool OPA_C, bool NARROW = false>
 static PartPlan plan_part(int m, int n, int k, int bn_cols, int num_cu, int min_rounds)
 {
-    using C_ = Cfg<CPLX, OPA_C>;
+    using C_ = Cfg<CPLX, OPA_C, NARROW>;
     if (bn_cols <= 0 || bn_cols > C_::BN) bn_cols = C_::BN;
     const long tiles = (long)((m + C_::BM - 1) / C_::BM) * ((n + bn_cols - 1) / bn_cols);
     const long slots = 2L * num_cu;                          // two workgroups per CU
@@ -879,29 +885,65 @@ static PartPlan plan_part(int m, int n, int k, int bn_cols, int num_cu, int min_
     return p;
 }
 
-// How a width n is covered by launches (launch_gemm_cols): one launch of whole tiles (+ guarded last tile), one launch of
-// "uniform ragged" tiles of bnu columns, or whole tiles + the ragged rest in a launch of its own.
-struct ColsPlan { int bnu; int n1; };                        // bnu > 0: uniform; n1 > 0: split at column n1; else single
+// How a width n is covered by launches (launch_gemm_cols): at most two pieces of columns, each one launch of tiles that all
+// have the same stride (bn_cols = 0: the tile width; 16 g: "uniform ragged" tiles of g 16-column groups) - a launch never mixes
+// whole and partial tiles (see launch_gemm_cols).  `narrow`: the piece runs on the 128 x 64 real tile.
+struct ColPiece { int c0, n, bn_cols; bool narrow; };
+struct ColsPlan { int npieces; ColPiece piece[2]; };
 template <bool CPLX, bool OPA_C> static int uniform_tile_cols(int m, int n, int k);
+static int real_narrow_mode()
+{
+    // 1 (default): narrow tiles for blocks of at most 64 columns and for the ragged rest of a width; 0: 128-wide tiles only
+    static const int mode = [] { const char* e = getenv("CHASE_HIP_REAL_NARROW"); return e ? atoi(e) : 1; }();
+    return mode;
+}
 template <bool CPLX, bool OPA_C>
-static ColsPlan plan_cols(int m, int n, int k)
+static ColsPlan plan_cols(int m, int n, int k, bool have_ws)
 {
     using C_ = Cfg<CPLX, OPA_C>;
+    const ColsPlan single{1, {{0, n, 0, false}, {0, 0, 0, false}}};
     const int rem = n % C_::BN;
-    const bool balanced = (C_::WAVES_N == 1);          // all waves span the tile width: skipped groups cost nobody
-    if (!(balanced && n > C_::BN && rem != 0 && rem <= C_::BN - 16)) return ColsPlan{0, 0};
-    const int bnu = uniform_tile_cols<CPLX, OPA_C>(m, n, k);
-    if (bnu > 0) return ColsPlan{bnu, 0};              // every column tile gets the same number of 16-column groups
-    return ColsPlan{0, n - rem};
+    if constexpr (!CPLX) {
+        const int mode = real_narrow_mode();
+        // uniform narrow tiles covering r columns: as few 64-wide tiles as hold its 16-column groups, the same number of
+        // groups in each
+        auto narrow_stride = [](int r) { const int ng = (r + 15) / 16, nt = (ng + 3) / 4; return 16 * ((ng + nt - 1) / nt); };
+        if (mode != 0 && n <= 64) return ColsPlan{1, {{0, n, narrow_stride(n), true}, {0, 0, 0, false}}};
+        if (!have_ws || n <= C_::BN || rem == 0) return single;
+        // The ragged rest of a width gets a launch of its own (a launch never mixes whole and partial tiles), K-split over
+        // the chip: up to 64 columns on ONE column of narrow tiles - measured at N = 32768 (profiles/r03_hemm_sweep.txt):
+        // 1.48 ms for one 16-column group (a pure stream over A at 5.8 TB/s), 2.0 ms for three, 2.4 ms for four, against
+        // 1.9 / 2.4 / 2.9 ms on the 128-wide tile with its two LDS stages; two columns of narrow tiles would stream A twice
+        // (4.2 ms for 72 columns against 3.3 ms), so a wider rest stays on the 128-wide ragged launch.  A rest of more than
+        // 112 columns fills its last tile well enough to stay in the one launch.
+        if (rem > C_::BN - 16) return single;
+        if (mode != 0 && rem <= 64) {
+            // cheaper than letting a partly idle 128-wide last tile ride along at a whole tile's cost? (fit of the numbers
+            // above: 0.75 passes over A + 0.68 of a group's whole-tile time per live group)
+            const double t_group = 2.0 * m * (double)k * 16.0 / 75.0e12;
+            const double t_pass = (double)m * k * 8.0 / 5.5e12;
+            const int g = (rem + 15) / 16;
+            if (mode == 2 || 0.75 * t_pass + 0.68 * g * t_group + 10e-6 < C_::TN * t_group)
+                return ColsPlan{2, {{0, n - rem, 0, false}, {n - rem, rem, 16 * g, true}}};
+            return single;
+        }
+        return ColsPlan{2, {{0, n - rem, 0, false}, {n - rem, rem, 0, false}}};
+    } else {
+        const bool balanced = (C_::WAVES_N == 1);      // all waves span the tile width: skipped groups cost nobody
+        if (!(have_ws && balanced && n > C_::BN && rem != 0 && rem <= C_::BN - 16)) return single;
+        const int bnu = uniform_tile_cols<CPLX, OPA_C>(m, n, k);
+        if (bnu > 0) return ColsPlan{1, {{0, n, bnu, false}, {0, 0, 0, false}}};   // every tile the same number of groups
+        return ColsPlan{2, {{0, n - rem, 0, false}, {n - rem, rem, 0, false}}};
+    }
 }
 
-template <bool CPLX, bool OPA_C, int TAG>
+template <bool CPLX, bool OPA_C, int TAG, bool NARROW = false>
 static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* alpha, const double* A, long lda,
                             const double* B, long ldb, const double* beta, double* C, long ldc,
                             double* ws, size_t ws_bytes, int num_cu, bool allow3m, const LaunchInfo& li,
                             int bn_cols = 0)
 {
-    using C_ = Cfg<CPLX, OPA_C>;
+    using C_ = Cfg<CPLX, OPA_C, NARROW>;
     if (m <= 0 || n <= 0) return 0;
     if (bn_cols <= 0 || bn_cols > C_::BN) bn_cols = C_::BN;
     GemmArgs a;
@@ -915,7 +957,7 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
     const int nkt = (k + C_::BK - 1) / C_::BK;
     // without a workspace nothing can be split; with one, the plan's slabs must fit - callers size the workspace with
     // gemm_f64_ws_need, which takes its numbers from the same plan
-    PartPlan pl = plan_part<CPLX, OPA_C>(m, n, k, bn_cols, num_cu, li.min_rounds);
+    PartPlan pl = plan_part<CPLX, OPA_C, NARROW>(m, n, k, bn_cols, num_cu, li.min_rounds);
     if (ws == nullptr) pl = PartPlan{(long)a.gm * a.gn, 0, 1, 0};
     if (pl.ws_bytes > ws_bytes) return (int)hipErrorInvalidValue;       // never split differently to fit: refuse
     const long full = pl.full, tail = pl.tail;
@@ -934,8 +976,8 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
     const int dev = (li.device >= 0 && li.device < MAX_DEVICES) ? li.device : 0;
     static std::atomic<bool> attr_set[MAX_DEVICES];
     if (!attr_set[dev].load(std::memory_order_relaxed)) {
-        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, false, false, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, true, false, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set[dev].store(true, std::memory_order_relaxed);
     }
     // complex HEMMs of the filter phase (tag 1) run the 3-product scheme unless CHASE_HIP_GEMM3M=0 / gemm3m_set(0);
@@ -958,8 +1000,8 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
         }
     }
     if (!(CAN3M && ok3m)) {
-        if (ragged) hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG, true, false>), dim3(grid), dim3(256), lds_bytes, st, a);
-        else        hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG, false, false>), dim3(grid), dim3(256), lds_bytes, st, a);
+        if (ragged) hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG, true, false, NARROW>), dim3(grid), dim3(256), lds_bytes, st, a);
+        else        hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG, false, false, NARROW>), dim3(grid), dim3(256), lds_bytes, st, a);
     }
     if (tail > 0) {
         hipLaunchKernelGGL((tail_reduce_kernel<CPLX, C_::BM, C_::BN>), dim3((unsigned)tail * TAIL_PARTS), dim3(256), 0, st, ws,
@@ -1004,19 +1046,22 @@ static int launch_gemm_cols(hipStream_t st, int m, int n, int k, const double* a
                             const double* B, long ldb, const double* beta, double* C, long ldc,
                             double* ws, size_t ws_bytes, int num_cu, bool allow3m, const LaunchInfo& li)
 {
-    using C_ = Cfg<CPLX, OPA_C>;
-    constexpr int EPT = C_::EPT;
-    const ColsPlan cp = ws != nullptr ? plan_cols<CPLX, OPA_C>(m, n, k) : ColsPlan{0, 0};
-    if (cp.bnu > 0)        // one launch, one pass over A
-        return launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, allow3m, li, cp.bnu);
-    if (cp.n1 > 0) {
-        const int n1 = cp.n1;
-        int rc = launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n1, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, allow3m, li);
+    constexpr int EPT = CPLX ? 2 : 1;
+    const ColsPlan cp = plan_cols<CPLX, OPA_C>(m, n, k, ws != nullptr);
+    for (int i = 0; i < cp.npieces; ++i) {
+        const ColPiece& pc = cp.piece[i];
+        const double* Bp = B + (long)pc.c0 * ldb * EPT;
+        double* Cp = C + (long)pc.c0 * ldc * EPT;
+        int rc;
+        if constexpr (!CPLX) {
+            if (pc.narrow) rc = launch_gemm_part<CPLX, OPA_C, TAG, true>(st, m, pc.n, k, alpha, A, lda, Bp, ldb, beta, Cp, ldc, ws, ws_bytes, num_cu, allow3m, li, pc.bn_cols);
+            else           rc = launch_gemm_part<CPLX, OPA_C, TAG, false>(st, m, pc.n, k, alpha, A, lda, Bp, ldb, beta, Cp, ldc, ws, ws_bytes, num_cu, allow3m, li, pc.bn_cols);
+        } else {
+            rc = launch_gemm_part<CPLX, OPA_C, TAG, false>(st, m, pc.n, k, alpha, A, lda, Bp, ldb, beta, Cp, ldc, ws, ws_bytes, num_cu, allow3m, li, pc.bn_cols);
+        }
         if (rc) return rc;
-        return launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n - n1, k, alpha, A, lda, B + (long)n1 * ldb * EPT, ldb, beta,
-                                                  C + (long)n1 * ldc * EPT, ldc, ws, ws_bytes, num_cu, allow3m, li);
     }
-    return launch_gemm_part<CPLX, OPA_C, TAG>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, allow3m, li);
+    return 0;
 }
 
 // The three-multiplication kernel has no guarded path: it needs whole 128-row tiles and whole 8-deep K tiles.  A filter
@@ -1068,11 +1113,20 @@ template <bool CPLX, bool OPA_C>
 static size_t ws_need(int m, int n, int k, int num_cu, int min_rounds)
 {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    auto part = [&](int nn, int bn_cols) { return plan_part<CPLX, OPA_C>(m, nn, k, bn_cols, num_cu, min_rounds).ws_bytes; };
-    const ColsPlan cp = plan_cols<CPLX, OPA_C>(m, n, k);
-    if (cp.bnu > 0) return part(n, cp.bnu);
-    if (cp.n1 > 0) return std::max(part(cp.n1, 0), part(n - cp.n1, 0));
-    return part(n, 0);
+    const ColsPlan cp = plan_cols<CPLX, OPA_C>(m, n, k, true);
+    size_t need = 0;
+    for (int i = 0; i < cp.npieces; ++i) {
+        const ColPiece& pc = cp.piece[i];
+        size_t b;
+        if constexpr (!CPLX) {
+            b = pc.narrow ? plan_part<CPLX, OPA_C, true>(m, pc.n, k, pc.bn_cols, num_cu, min_rounds).ws_bytes
+                          : plan_part<CPLX, OPA_C, false>(m, pc.n, k, pc.bn_cols, num_cu, min_rounds).ws_bytes;
+        } else {
+            b = plan_part<CPLX, OPA_C, false>(m, pc.n, k, pc.bn_cols, num_cu, min_rounds).ws_bytes;
+        }
+        need = std::max(need, b);
+    }
+    return need;
 }
 
 size_t gemm_f64_ws_need(bool cplx, char opA, int m, int n, int k, int num_cu, int min_rounds)

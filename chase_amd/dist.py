@@ -274,6 +274,10 @@ class DistSolver:
         from .capi import set_iteration_hook
         set_iteration_hook(self, fn)
 
+    def recompute_residuals(self, ncols, lam=None):
+        from .capi import recompute_residuals
+        return recompute_residuals(self, ncols, lam)
+
     def local_V(self):
         out = np.empty((self.m_loc, self.ncol), dtype=self.dt, order="F")
         check(lib.chase_hip_psolver_download_v(self.h, out.ctypes.data, self.m_loc), "download_v")

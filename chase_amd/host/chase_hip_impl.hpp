@@ -47,6 +47,10 @@ struct HipImplExtras {
     virtual void reset_counters() = 0;
     virtual void* device_V1() = 0;               // current (local) vector block, pending swaps applied
     virtual std::size_t local_rows() const = 0;
+    // out[j] = || H v_j - lambda_j v_j ||_2 for the first ncols vectors the Impl holds, from a FRESH four-product H V
+    // (never from products a previous step left behind): what the reference's solve tests recompute after a solve
+    // (tests/chase_serial_solve.cpp:144-148,195-199, tests/chase_distributed_solve.cpp:209-284)
+    virtual void recompute_residuals(std::size_t ncols, const double* lambda, double* out) = 0;
 };
 
 template <class T, class BaseT = ChaseBase<T>, class ConfigT = ChaseConfig<T>>
@@ -310,6 +314,17 @@ public:
         }
         hip_ok(chase_hip_resid_norms(ctx_, CP, (int)N_, (int)sub, W, (long)N_, V, (long)N_, ritzv, resd, 0), "resid");
         if (resd != resid_.data() + locked_) std::memcpy(resid_.data() + locked_, resd, sub * sizeof(R));
+    }
+
+    void recompute_residuals(std::size_t ncols, const double* lambda, double* out) override
+    {
+        if (ncols > nevex_) throw std::invalid_argument("recompute_residuals: more columns than the Impl holds");
+        flush_swaps();
+        hv_valid_ = false;                                                   // dV2_ is scratch from here on
+        chase_hip_ctx_set_phase(ctx_, 2);                                    // four real products per complex product
+        gemm('N', N_, ncols, N_, T(1), dH_, ldd_h_, dV1_, N_, T(0), dV2_, N_);
+        chase_hip_ctx_set_phase(ctx_, 0);
+        hip_ok(chase_hip_resid_norms(ctx_, CP, (int)N_, (int)ncols, dV2_, (long)N_, dV1_, (long)N_, lambda, out, 0), "resid");
     }
 
     void Swap(std::size_t i, std::size_t j) override

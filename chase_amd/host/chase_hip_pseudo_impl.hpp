@@ -249,6 +249,16 @@ public:
         if (resd != resid_.data() + locked_) std::memcpy(resid_.data() + locked_, resd, sub * sizeof(R));
     }
 
+    void recompute_residuals(std::size_t ncols, const double* lambda, double* out) override
+    {
+        if (ncols > 2 * nevex_) throw std::invalid_argument("recompute_residuals: more columns than the Impl holds");
+        flush_swaps();
+        chase_hip_ctx_set_phase(ctx_, 2);
+        gemm('N', N_, ncols, N_, T(1), dH_, ldd_h_, dV1_, N_, T(0), dV2_, N_);
+        chase_hip_ctx_set_phase(ctx_, 0);
+        hip_ok(chase_hip_resid_norms(ctx_, CP, (int)N_, (int)ncols, dV2_, (long)N_, dV1_, (long)N_, lambda, out, 0), "resid");
+    }
+
     void Swap(std::size_t i, std::size_t j) override
     {
         if (i == j) return;

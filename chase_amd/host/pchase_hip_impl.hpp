@@ -84,7 +84,9 @@ public:
         pack_elems_ = nc_ * nc_ + 64 * nc_ + 64;                    // packed Gram triangle / agreement scratch
         alloc((void**)&dPack_, pack_elems_ * sizeof(T));
         // staging must hold the largest block of ANY rank (rank 0 of a dimension owns the most rows)
-        alloc((void**)&dStage_, (std::size_t)std::max(Rr_.count(0), Cc_.count(0)) * nc_ * sizeof(T));
+        // staging of the column <-> row redistribution: the pieces of ALL source ranks side by side (they add up to the rows
+        // of the destination block), so that the broadcasts can be in flight together
+        alloc((void**)&dStage_, (std::size_t)std::max(std::max(Rr_.count(0), Cc_.count(0)), (long)std::max(m_, n_)) * nc_ * sizeof(T));
         dHbac_ = dH_; ldhbac_ = ldh_;
         // column panel of the pipelined HEMM: a panel's GEMM should fill the chip once with whole output tiles
         // (128-row tiles x 64 / 128 columns, two workgroups on each of the 256 CUs) in both directions; the panel grid is
@@ -310,8 +312,14 @@ public:
     {
         flush_swaps(); sync_comm();
         const std::size_t c0 = locked_;
-        // replicas of V over the grid columns are re-synchronised like the reference does (pchase_gpu.hpp:1631-1633)
-        coll(chase_hip_grid_bcast(grid_, CHASE_HIP_ROW, dV1_ + c0 * m_, m_ * block * E, 0, 0));
+        // The reference re-broadcasts V inside the row group here so that the replicas over the grid columns are bitwise
+        // equal (pchase_gpu.hpp:1631-1633; 0.67 GB per call at config 4).  Not needed for agreement: every V the filter
+        // produces comes out of an all-reduce over that very row group (identical bits on its members), the Ritz pairs,
+        // potrf info, residuals and bounds are agreed explicitly (agree_vector / agree_max), and what a QR pass may leave
+        // between the replicas - last-bit differences from the two column groups' separate Gram all-reduces - is erased by
+        // the next filter step's row-group all-reduce.  CHASE_HIP_RR_RESYNC=1 restores the broadcast (debugging).
+        static const bool resync = [] { const char* e = std::getenv("CHASE_HIP_RR_RESYNC"); return e && std::atoi(e) != 0; }();
+        if (resync) coll(chase_hip_grid_bcast(grid_, CHASE_HIP_ROW, dV1_ + c0 * m_, m_ * block * E, 0, 0));
         hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)block, dV1_ + c0 * m_, (long)m_, dV2_ + c0 * m_, (long)m_), "lacpy");
         chase_hip_ctx_set_phase(ctx_, 2);                                    // H-times-block product outside the filter
         hemm_dir(true, c0, block, T(1), T(0), false);                        // W1 = H^H V1 (row-type), all-reduced
@@ -361,6 +369,27 @@ public:
         for (std::size_t i = 0; i < sub; ++i) resd[i] = std::sqrt(resd[i]);
         agree_vector(resd, sub, nullptr, 0);
         if (resd != resid_.data() + locked_) std::memcpy(resid_.data() + locked_, resd, sub * sizeof(R));
+    }
+
+    // the reference's residual step as it stands (mpi/residuals.hpp:61-107: H V, column -> row redistribution of V, local
+    // sums of squares, all-reduce over the row group) on the first ncols vectors, never from cached products
+    void recompute_residuals(std::size_t ncols, const double* lambda, double* out) override
+    {
+        if (ncols > nc_) throw std::invalid_argument("recompute_residuals: more columns than the Impl holds");
+        flush_swaps(); sync_comm();
+        hv_valid_ = false;                                                   // dW1_ / dW2_ are scratch from here on
+        hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)ncols, dV1_, (long)m_, dV2_, (long)m_), "lacpy");
+        chase_hip_ctx_set_phase(ctx_, 2);
+        hemm_ptr(true, dV1_, dW1_, 0, ncols, T(1), T(0), false);             // W1 = H^H V1 (row-type), all-reduced
+        chase_hip_ctx_set_phase(ctx_, 0);
+        redistribute_c2r(dV2_, dW2_, ncols);
+        std::vector<double> sq(ncols);
+        hip_ok(chase_hip_resid_norms(ctx_, CP, (int)n_, (int)ncols, dW1_, (long)n_, dW2_, (long)n_, lambda, sq.data(), 1), "resid_norms");
+        double* d = (double*)dPack_;
+        hip_ok(chase_hip_memcpy_h2d(ctx_, d, sq.data(), ncols * sizeof(double)), "h2d");
+        coll(chase_hip_grid_allreduce(grid_, CHASE_HIP_ROW, d, ncols, 0));
+        hip_ok(chase_hip_memcpy_d2h(ctx_, sq.data(), d, ncols * sizeof(double)), "d2h");
+        for (std::size_t i = 0; i < ncols; ++i) out[i] = std::sqrt(sq[i]);
     }
 
     void Swap(std::size_t i, std::size_t j) override
@@ -466,24 +495,28 @@ protected:
             rowmap_cnt_.push_back((int)gl.size());
         }
     }
-    // dst (row-type, ld n_) <- src (column-type, ld m_), ncols columns
-    void redistribute_c2r(const T* src, T* dst, std::size_t ncols)
-    {
-        for (const Xfer& x : c2r_) {
-            if (myrow_ == x.root)
-                hip_ok(chase_hip_rows_indexed(ctx_, CP, src, (long)m_, dStage_, x.cnt, x.d_src, x.cnt, (int)ncols, 0), "pack");
-            coll(chase_hip_grid_bcast(grid_, CHASE_HIP_COL, dStage_, (std::size_t)x.cnt * ncols * E, x.root, 0));
-            hip_ok(chase_hip_rows_indexed(ctx_, CP, dStage_, x.cnt, dst, (long)n_, x.d_dst, x.cnt, (int)ncols, 1), "unpack");
-        }
-    }
+    // dst (row-type, ld n_) <- src (column-type, ld m_), ncols columns.  The reference issues one broadcast per contiguous run
+    // of rows (distMultiVector.hpp:2658-2718); here one packed broadcast per source rank, all of them issued back to back on
+    // the communication stream (each into its own piece of the staging block) with ONE wait of the compute stream
+    void redistribute_c2r(const T* src, T* dst, std::size_t ncols) { redistribute(c2r_, CHASE_HIP_COL, myrow_, src, m_, dst, n_, ncols); }
     // dst (column-type, ld m_) <- src (row-type, ld n_)
-    void redistribute_r2c(const T* src, T* dst, std::size_t ncols)
+    void redistribute_r2c(const T* src, T* dst, std::size_t ncols) { redistribute(r2c_, CHASE_HIP_ROW, mycol_, src, n_, dst, m_, ncols); }
+    void redistribute(const std::vector<Xfer>& plan, int group, int me, const T* src, std::size_t lds, T* dst, std::size_t ldd,
+                      std::size_t ncols)
     {
-        for (const Xfer& x : r2c_) {
-            if (mycol_ == x.root)
-                hip_ok(chase_hip_rows_indexed(ctx_, CP, src, (long)n_, dStage_, x.cnt, x.d_src, x.cnt, (int)ncols, 0), "pack");
-            coll(chase_hip_grid_bcast(grid_, CHASE_HIP_ROW, dStage_, (std::size_t)x.cnt * ncols * E, x.root, 0));
-            hip_ok(chase_hip_rows_indexed(ctx_, CP, dStage_, x.cnt, dst, (long)m_, x.d_dst, x.cnt, (int)ncols, 1), "unpack");
+        std::size_t off = 0;
+        for (const Xfer& x : plan) {
+            T* piece = dStage_ + off;
+            if (me == x.root)
+                hip_ok(chase_hip_rows_indexed(ctx_, CP, src, (long)lds, piece, x.cnt, x.d_src, x.cnt, (int)ncols, 0), "pack");
+            coll(chase_hip_grid_bcast(grid_, group, piece, (std::size_t)x.cnt * ncols * E, x.root, 1));
+            off += (std::size_t)x.cnt * ncols;
+        }
+        sync_comm();
+        off = 0;
+        for (const Xfer& x : plan) {
+            hip_ok(chase_hip_rows_indexed(ctx_, CP, dStage_ + off, x.cnt, dst, (long)ldd, x.d_dst, x.cnt, (int)ncols, 1), "unpack");
+            off += (std::size_t)x.cnt * ncols;
         }
     }
 

@@ -387,6 +387,12 @@ int chase_hip_op_check_symmetry(chase_hip_solver* s, int* is_sym)
     return guarded("checkSymmetryEasy", [&] { DISPATCH(s, *is_sym = k.checkSymmetryEasy() ? 1 : 0); });
 }
 /* copies the current device V1 (N x nevex) to a host buffer without ending the solve (tests) */
+int chase_hip_solver_recompute_residuals(chase_hip_solver* s, size_t ncols, const double* lambda, double* resid)
+{
+    if (!s || !lambda || !resid) return chase_hip::set_error(CHASE_HIP_EINVAL, "recompute_residuals: NULL argument");
+    return guarded("recompute_residuals", [&] { s->ex->recompute_residuals(ncols, lambda, resid); });
+}
+
 int chase_hip_solver_peek_v(chase_hip_solver* s, chase_hip_ctx* ctx, void* host, size_t ldh)
 {
     return guarded("peek_v", [&] {

@@ -44,6 +44,8 @@ const char* chase_hip_last_error(void);
 /* name may be NULL.  clock_khz is the reported max engine clock. */
 int chase_hip_device_info(chase_hip_ctx* ctx, int* num_cu, int* clock_khz, size_t* hbm_bytes, char* name,
                           int name_len);
+/* PCI bus id ("0000:05:00.0") of the context's device: which physical GPU a rank ended up on, whatever the visibility lists */
+int chase_hip_device_bus_id(chase_hip_ctx* ctx, char* out, int len);
 const char* chase_hip_version(void);
 /* HIP devices visible to this process (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES applied); 0 without a GPU */
 int chase_hip_device_count(void);

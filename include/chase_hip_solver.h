@@ -70,6 +70,11 @@ int chase_hip_solver_lanczos_for_h2(chase_hip_solver* s, int numvec, int m, doub
 int chase_hip_solver_stats(chase_hip_solver* s, chase_hip_stats* out);
 const double* chase_hip_solver_resid(chase_hip_solver* s); /* nev+nex residuals (host) */
 const char* chase_hip_solver_trace(chase_hip_solver* s);   /* '\n'-separated virtual-call trace of the last solve */
+/* resid[j] = || H v_j - lambda[j] v_j ||_2 for the first ncols vectors the Impl holds (after a solve: the eigenvectors),
+ * from a fresh four-product H V - never from products an earlier step left behind.  The independent check the reference's
+ * solve tests make after a solve (tests/chase_serial_solve.cpp:144-148,195-199, tests/chase_distributed_solve.cpp:209-284).
+ * Collective over the grid for the distributed Impls. */
+int chase_hip_solver_recompute_residuals(chase_hip_solver* s, size_t ncols, const double* lambda, double* resid);
 int chase_hip_solver_peek_v(chase_hip_solver* s, chase_hip_ctx* ctx, void* host, size_t ldh);
 
 /* the ChaseBase virtuals */

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes over the single-kernel HEMM driver (one counter group per rocprofv3 run; no trace domains besides kernel-trace).
-# usage: scripts/prof_pmc.sh <out.txt> <dev_gemm_only args...>
+# usage: [PMC_DRIVER=scripts/dev_panel_only.py] scripts/prof_pmc.sh <out.txt> <driver args...>   (default driver: dev_gemm_only.py)
 OUT=$(realpath -m "$1"); shift
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
@@ -21,7 +21,7 @@ if [ -n "${PMC_GROUPS:-}" ]; then IFS=';' read -r -a GROUPS_ <<< "$PMC_GROUPS"; 
 i=0
 for g in "${GROUPS_[@]}"; do
   d=/tmp/pmc_$i; rm -rf $d
-  rocprofv3 --kernel-trace --pmc $g -f csv -d $d -- python3 $REPO/scripts/dev_gemm_only.py "$@" > /tmp/pmc_$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $g -f csv -d $d -- python3 $REPO/${PMC_DRIVER:-scripts/dev_gemm_only.py} "$@" > /tmp/pmc_$i.log 2>&1
   f=$(find $d -name "*counter_collection.csv" | head -1)
   echo "## group: $g" >> "$OUT"
   python3 - "$f" >> "$OUT" <<'PY'
@@ -29,7 +29,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 acc = collections.defaultdict(list)
 for r in rows:
-    if "gemm_f64_kernel" in r["Kernel_Name"]:
+    if "gemm_f64_kernel" in r["Kernel_Name"] or "tail_reduce" in r["Kernel_Name"]:
         acc[(r["Kernel_Name"][:60], r["Counter_Name"])].append(float(r["Counter_Value"]))
 for (k, c), v in sorted(acc.items()):
     print(f"{c:28s} launches={len(v):3d} mean={sum(v)/len(v):.6g}  kernel={k}")

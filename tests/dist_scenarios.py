@@ -226,7 +226,10 @@ def scenario_solve(ctx, grid, comm, N, nev, nex, cplx, mb, deg):
     for (i, j, blk) in objs:
         if j == 0:
             V[rl.globals_of(i), :] = blk
-    assert np.max(O.residuals(H, lam, V)) < 1e-8
+    r_host = O.residuals(H, lam, V)
+    assert np.max(r_host) < 1e-8
+    r_dev = s.recompute_residuals(nev)               # mpi/residuals.hpp on the grid, from a fresh four-product H V
+    assert np.max(np.abs(r_dev - r_host)) <= 1e-12 * np.abs(H).max() and np.max(r_dev) < 1e-8
     assert O.orthogonality(V) < 1e-9
     assert abs(st["iterations"] - so["iterations"]) <= 2, (st["iterations"], so["iterations"])
     # every rank holds identical Ritz values (control-flow agreement)
@@ -443,7 +446,9 @@ def scenario_pseudo_solve(ctx, grid, comm, mb):
     assert np.all(np.isfinite(lam)) and np.all(np.isfinite(resid))
     assert np.max(resid) <= 1e-10
     V = gathered_V(s, grid, rl, comm, N, H.dtype)[:, :nev]
-    assert np.max(np.linalg.norm(H @ V - V * lam[None, :], axis=0)) <= 1e-10
+    r_host = np.linalg.norm(H @ V - V * lam[None, :], axis=0)
+    assert np.max(r_host) <= 1e-10
+    assert np.max(np.abs(s.recompute_residuals(nev) - r_host)) <= 1e-12          # H v = S H^H S v through the folded matrix
     assert np.max(np.abs(lam - pos[:nev])) <= 1e-9
     assert st["locked"] >= nev
     allv = comm.all_gather_object(lam)

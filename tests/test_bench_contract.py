@@ -69,3 +69,47 @@ def test_multi_rank_launch_starts_its_own_ranks_and_fails_only_for_lack_of_a_dev
     assert "no usable device context" in p.stderr and "no HIP device visible" in p.stderr
     assert "RANK expected" not in p.stderr and "environment variable" not in p.stderr
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_rank_environment_binds_one_device_per_rank():
+    """A rank's runtime sees ITS device only (the reference: device = node-local rank, grid/mpiGrid2D.hpp:225-233); an existing
+    visibility list is honoured entry by entry; CHASE_HIP_BIND=0 and the shared-device test transport leave the lists alone."""
+    env = {}
+    assert B.bind_one_device(env, 3) in ("3", str(3 % max(B.kfd_gpu_count(), 1)) if B.kfd_gpu_count() else "3")
+    assert "HIP_VISIBLE_DEVICES" not in env and env["CHASE_HIP_BOUND_DEVICE"] == env["ROCR_VISIBLE_DEVICES"]
+    env = {"ROCR_VISIBLE_DEVICES": "4,5,6,7"}
+    assert B.bind_one_device(env, 2) == "6" and env["ROCR_VISIBLE_DEVICES"] == "6"
+    env = {"HIP_VISIBLE_DEVICES": "1,3", "ROCR_VISIBLE_DEVICES": "4,5,6,7", "CUDA_VISIBLE_DEVICES": "0"}
+    assert B.bind_one_device(env, 1) == "7"                      # HIP's entry 3 indexes the runtime's list
+    assert "HIP_VISIBLE_DEVICES" not in env and "CUDA_VISIBLE_DEVICES" not in env
+    env = {"CHASE_HIP_BIND": "0", "HIP_VISIBLE_DEVICES": "0,1"}
+    assert B.bind_one_device(env, 1) is None and env == {"CHASE_HIP_BIND": "0", "HIP_VISIBLE_DEVICES": "0,1"}
+    env = {"CHASE_HIP_TRANSPORT": "host"}
+    assert B.bind_one_device(env, 1) is None and "ROCR_VISIBLE_DEVICES" not in env
+
+
+def test_spawned_ranks_carry_the_binding(monkeypatch):
+    """spawn_ranks hands child r an environment whose runtime visibility is device r - set before the child starts"""
+    seen = []
+
+    class FakePopen:
+        def __init__(self, cmd, env=None, **kw):
+            seen.append(env)
+        def poll(self): return 0
+        def terminate(self): pass
+        def kill(self): pass
+
+    monkeypatch.setattr(B.subprocess, "Popen", FakePopen)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("CHASE_HIP_TRANSPORT", raising=False)
+    monkeypatch.setattr(B, "kfd_gpu_count", lambda: 8)
+
+    class A:
+        gpus = 4
+    rc = B.spawn_ranks(A, ["--gpus", "4"])
+    assert rc == 1                                           # no result line from fake ranks
+    assert [e["ROCR_VISIBLE_DEVICES"] for e in seen] == ["0", "1", "2", "3"]
+    assert [e["LOCAL_RANK"] for e in seen] == ["0", "1", "2", "3"] and all(e["WORLD_SIZE"] == "4" for e in seen)
+    assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in seen)

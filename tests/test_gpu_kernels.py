@@ -73,6 +73,36 @@ def test_filter_phase_gemm_3m_matches_numpy(ctx, op, shape):
         lib.chase_hip_ctx_set_phase(ctx.h, 0)
 
 
+@pytest.mark.parametrize("op", ["N", "C"])
+@pytest.mark.parametrize("phase", [0, 1])
+@pytest.mark.parametrize("shape", [(256, 40, 512), (384, 64, 1024), (130, 33, 77), (256, 5, 8192), (1024, 48, 4096),
+                                   (128, 17, 16), (2048, 133, 2048), (4096, 300, 4096), (4096, 200, 4100), (513, 60, 1000)])
+def test_real_narrow_tile_matches_numpy(ctx, op, phase, shape):
+    """Real products on the 128 x 64 tile (three LDS stages, software-pipelined K loop): blocks of at most 64 columns and the
+    ragged rest of a width (133 = 128 + 5, 300 = 256 + 44, 200 = 128 + 72 in two narrow tiles of 48); LDS-DMA path (whole row
+    tiles, even leading dimensions) and the guarded register path (ragged M, partial K tile), K-split tails, beta != 0."""
+    from chase_amd.capi import lib
+    m, n, k = shape
+    rng = np.random.default_rng(991 + m + 3 * n + 7 * k)
+    A = rnd(rng, (m, k) if op == "N" else (k, m), False)
+    B = rnd(rng, (k, n), False)
+    Cm = rnd(rng, (m, n), False)
+    opA = A if op == "N" else A.T
+    lib.chase_hip_ctx_set_phase(ctx.h, phase)
+    try:
+        for beta in (0.0, -0.4):
+            dA, dB, dC = ctx.array(A), ctx.array(B), ctx.array(Cm)
+            ctx.gemm(op, m, n, k, 0.7, dA.ptr, dA.ld, dB.ptr, dB.ld, beta, dC.ptr, dC.ld, False)
+            got = dC.download()
+            ref = 0.7 * (opA @ B) + beta * Cm
+            scale = 0.7 * (np.abs(opA) @ np.abs(B)) + abs(beta) * np.abs(Cm) + 1e-300
+            assert np.max(np.abs(got - ref) / scale) < GEMM_TOL
+            for d in (dA, dB, dC):
+                d.free()
+    finally:
+        lib.chase_hip_ctx_set_phase(ctx.h, 0)
+
+
 def test_gemm_beta_zero_ignores_nan_in_c(ctx):
     rng = np.random.default_rng(0)
     A, B = rnd(rng, (64, 32), False), rnd(rng, (32, 16), False)

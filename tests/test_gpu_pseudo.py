@@ -77,7 +77,9 @@ def test_solve_pseudo_bse_fixture(ctx):
     assert np.all(np.isfinite(lam)) and np.all(np.isfinite(resid))
     assert np.max(resid) <= 1e-10                                         # the reference's assertion
     V = s.V[:, :nev]
-    assert np.max(np.linalg.norm(H @ V - V * lam[None, :], axis=0)) <= 1e-10   # recomputed like the reference test
+    r_host = np.linalg.norm(H @ V - V * lam[None, :], axis=0)
+    assert np.max(r_host) <= 1e-10                                         # recomputed like the reference test
+    assert np.max(np.abs(s.recompute_residuals(nev) - r_host)) <= 1e-12    # the library's own independent check
     assert np.max(np.abs(lam - pos[:nev])) <= 1e-9                         # fixture spectrum: smallest positive eigenvalues
     k = O.OraclePseudoCPU(H, nev, nex); k.config.num_lanczos = 10; k.config.lanczos_iter = 50
     so = O.solve_pseudo(k)
