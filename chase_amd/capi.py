@@ -256,6 +256,7 @@ _sig("chase_hip_houseqr", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long
 _sig("chase_hip_heevd", c_int, c_void_p, c_int, c_int, c_void_p, c_long, c_void_p)
 _sig("chase_hip_heevd_gpu", c_int, c_void_p, c_int, c_int, c_void_p, c_long, c_void_p)
 _sig("chase_hip_heevd_host", c_int, c_int, c_int, c_void_p, c_long, c_void_p)
+_sig("chase_hip_stedc", c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long)
 _sig("chase_hip_stemr_host", c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int)
 _sig("chase_hip_col_dot", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p)
 _sig("chase_hip_col_nrm2", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p)

@@ -497,6 +497,12 @@ int chase_hip_stemr_host(int n, double* d, double* e, double* w, double* Z, int 
 {
     return host_stemr(n, d, e, w, Z, ldz);
 }
+int chase_hip_stedc(chase_hip_ctx* c, int n, const double* d_host, const double* e_host, double* w_host, double* Z_dev, long ldz)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "stedc: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    return stedc_gpu(c, n, d_host, e_host, w_host, Z_dev, ldz);
+}
 
 /* ---- batched column (multi-vector) level-1 kernels with device-resident scalars ------------------------------ */
 int chase_hip_col_dot(chase_hip_ctx* c, int cplx, int m, int n, const void* X, long ldx, const void* Y, long ldy,

@@ -543,8 +543,9 @@ extern "C" int chase_hip_heevd_gpu(chase_hip_ctx* c, int cplx_, int n, void* A_,
             if (cplx) HK(hipLaunchKernelGGL(ltrd_colupd_kernel<true>, dim3(1), dim3(256), 0, st, A, lda, n, n - 1, 0, Xp, tau, dots, 0, npart, dd));
             else      HK(hipLaunchKernelGGL(ltrd_colupd_kernel<false>, dim3(1), dim3(256), 0, st, A, lda, n, n - 1, 0, Xp, tau, dots, 0, npart, dd));
         }
-        // tridiagonal eigenproblem on the host
-        std::vector<double> hd(n), hee(n), hz((size_t)n * n);
+        // tridiagonal eigenproblem: divide & conquer with its O(n^2) / O(n^3) parts on the device (stedc_gpu.hip); on the host
+        // (LAPACK dstedc / dstemr, eigenvectors uploaded) below CHASE_HIP_STEDC_GPU_MIN rows (default 512; 0: always host)
+        std::vector<double> hd(n), hee(n), hz;
         HC(hipMemcpyAsync(hd.data(), dd, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
         HC(hipMemcpyAsync(hee.data(), de, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, st));
         HC(hipStreamSynchronize(st));
@@ -553,12 +554,19 @@ extern "C" int chase_hip_heevd_gpu(chase_hip_ctx* c, int cplx_, int n, void* A_,
         // divide & conquer: threaded GEMMs inside, eigenvectors orthogonal to ~eps (MRRR gives ~1e-13 at n = 2560)
         static const bool use_mrrr = getenv("CHASE_HIP_TRIDIAG_MRRR") != nullptr;
         static const bool dbg = getenv("CHASE_HIP_HEEVD_TIMING") != nullptr;
+        static const int dc_min = [] { const char* e = getenv("CHASE_HIP_STEDC_GPU_MIN"); return e ? atoi(e) : 512; }();
         auto t1 = std::chrono::steady_clock::now();
-        int r2 = use_mrrr ? host_stemr(n, hd.data(), hee.data(), w_host, hz.data(), n)
+        int r2;
+        if (!use_mrrr && dc_min > 0 && n >= dc_min) {
+            r2 = stedc_gpu(c, n, hd.data(), hee.data(), w_host, Zr, n);
+        } else {
+            hz.resize((size_t)n * n);
+            r2 = use_mrrr ? host_stemr(n, hd.data(), hee.data(), w_host, hz.data(), n)
                           : host_stedc(n, hd.data(), hee.data(), w_host, hz.data(), n);
+            if (!r2) HC(hipMemcpyAsync(Zr, hz.data(), szZ * sizeof(double), hipMemcpyHostToDevice, st));
+        }
         auto t2 = std::chrono::steady_clock::now();
         if (r2) return r2;
-        HC(hipMemcpyAsync(Zr, hz.data(), szZ * sizeof(double), hipMemcpyHostToDevice, st));
         if (cplx) HK(hipLaunchKernelGGL(real_to_T_kernel<true>, dim3(1024), dim3(256), 0, st, Zr, Zc, (long)szZ));
         else      HK(hipLaunchKernelGGL(real_to_T_kernel<false>, dim3(1024), dim3(256), 0, st, Zr, Zc, (long)szZ));
         // eigenvectors = Q Z with Q = H_0 ... H_{n-2} acting on rows 1..n-1: the reflectors sit in B = A[1:, 0:n-1] in the
@@ -571,7 +579,7 @@ extern "C" int chase_hip_heevd_gpu(chase_hip_ctx* c, int cplx_, int n, void* A_,
         if (dbg) {
             auto t3 = std::chrono::steady_clock::now();
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-            fprintf(stderr, "heevd_gpu n=%d: tridiag %.1f ms, host tridiagonal eig %.1f ms, back-transform %.1f ms\n", n,
+            fprintf(stderr, "heevd_gpu n=%d: tridiag %.1f ms, tridiagonal eig %.1f ms, back-transform %.1f ms\n", n,
                     ms(t_start, t0b), ms(t1, t2), ms(t2, t3));
         }
         return 0;

@@ -34,6 +34,9 @@ int rows_indexed(hipStream_t st, bool cplx, const double* in, long ld_in, double
                  int np, int ncols, int scatter);
 int copy_cols_indexed(hipStream_t st, const double* src, long ld_src_d, double* dst, long ld_dst_d, long md,
                       const int* src_idx_dev, const int* dst_idx_dev, int cnt);
+// dst column dst0 + c <- src column src_idx[c], c < cnt (md doubles per column)
+int copy_cols_indexed_range(hipStream_t st, const double* src, long ld_src_d, double* dst, long ld_dst_d, long md,
+                            const int* src_idx_dev, int dst0, int cnt);
 int resid_norms(hipStream_t st, const double* W, long ldw_d, const double* V, long ldv_d, const double* lambda_dev,
                 long md, int ncols, double* out_dev, int do_sqrt);
 int sqrt_inplace(hipStream_t st, double* x, int n);
@@ -57,6 +60,12 @@ int gen_clement(hipStream_t st, bool cplx, double* H, long ldh, int mloc, int nl
                 long roff, int nb, int pc, int pj, long coff, double scale, double perturb, unsigned long long seed);
 int gen_bse(hipStream_t st, bool cplx, double* H, long ldh, int mloc, int nloc, long N, int mb, int pr, int pi, int nb,
             int pc, int pj, double dmin, double dmax, double offdiag, unsigned long long seed);
+
+// ---- tridiagonal divide & conquer with the O(n^2) / O(n^3) parts on the device (stedc_gpu.hip); d, e on the host ----
+}
+struct chase_hip_ctx;
+namespace chase_hip {
+int stedc_gpu(chase_hip_ctx* c, int n, const double* d, const double* e, double* w_host, double* Z_dev, long ldz);
 
 // ---- factorisation cores (factor_kernels.hip) ----
 int potf2_trtri(hipStream_t st, bool cplx, double* A, long lda, int nb, int joff, double* Tinv, int* info_dev);

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void copy_cols_indexed_kernel(const double* __
 {
     for (int c = blockIdx.y; c < cnt; c += gridDim.y) {
         const double* s = src + (long)src_idx[c] * lds_;
-        double* d = dst + (long)dst_idx[c] * ldd;
+        double* d = dst + (long)(dst_idx ? dst_idx[c] : c) * ldd;
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < md; i += (long)gridDim.x * 256) d[i] = s[i];
     }
 }
@@ -411,6 +411,14 @@ int copy_cols_indexed(hipStream_t st, const double* src, long ld_src_d, double* 
     if (cnt <= 0 || md <= 0) return 0;
     hipLaunchKernelGGL(copy_cols_indexed_kernel, grid2(md, cnt), dim3(256), 0, st, src, ld_src_d, dst, ld_dst_d, md,
                        src_idx_dev, dst_idx_dev, cnt);
+    return (int)hipGetLastError();
+}
+int copy_cols_indexed_range(hipStream_t st, const double* src, long ld_src_d, double* dst, long ld_dst_d, long md,
+                            const int* src_idx_dev, int dst0, int cnt)
+{
+    if (cnt <= 0 || md <= 0) return 0;
+    hipLaunchKernelGGL(copy_cols_indexed_kernel, grid2(md, cnt), dim3(256), 0, st, src, ld_src_d, dst + (long)dst0 * ld_dst_d,
+                       ld_dst_d, md, src_idx_dev, (const int*)nullptr, cnt);
     return (int)hipGetLastError();
 }
 int rows_indexed(hipStream_t st, bool cplx, const double* in, long ld_in, double* out, long ld_out, const int* idx_dev,

@@ -198,6 +198,13 @@ int chase_hip_set_identity(chase_hip_ctx* ctx, int cplx, int n, void* A, long ld
 int chase_hip_heevd_host(int cplx, int n, void* A_host, long lda, double* w_host); /* host-only twin (provider check) */
 /* host-only: all eigenpairs of a symmetric tridiagonal (Lanczos; lapackpp::t_stemr, cpu/lanczos.hpp:188) */
 int chase_hip_stemr_host(int n, double* d, double* e, double* w, double* Z, int ldz);
+/* Real symmetric tridiagonal eigenproblem by divide & conquer with the O(n^2) / O(n^3) parts on the device (secular equation,
+ * Gu-Eisenstat vectors, merge GEMMs; deflation and the leaves on the host): d (n), e (n-1) on the host, eigenvalues ascending
+ * to w_host, eigenvectors (n x n real, ldz) to DEVICE memory.  What chase_hip_heevd_gpu uses between its tridiagonalisation and
+ * back-transformation for n >= CHASE_HIP_STEDC_GPU_MIN (512).  Replaces the tridiagonal stage of cusolverDnXheevd
+ * (linalg/internal/nccl/rayleighRitz.hpp:170-173). */
+int chase_hip_stedc(chase_hip_ctx* ctx, int n, const double* d_host, const double* e_host, double* w_host, double* Z_dev,
+                    long ldz);
 
 /* ---- batched multi-vector level-1 kernels with device-resident scalars (Lanczos; cuda/lanczos_kernels.cu) ------- */
 /* out_dev[j] = X_j^H Y_j (complex: 2 doubles per column) */

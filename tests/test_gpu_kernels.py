@@ -579,3 +579,46 @@ def test_filter_gemm_of_arbitrary_size_uses_3m_for_the_bulk(ctx, op, m, k, n):
     assert m1 - m0 == 2.0 * 4 * m * n * k and 0.75 < ratio < 0.80, ratio
     for d in (dA, dB, dC):
         d.free()
+
+
+def _tridiag_cases(n, rng):
+    m = (n - 1) // 2
+    dg = np.concatenate([np.abs(np.arange(21) - 10.0)] * (n // 21))
+    eg = np.ones(len(dg) - 1); eg[20::21] = 1e-8
+    ez = rng.standard_normal(n - 1); ez[::7] = 0.0
+    k = np.arange(1, n)
+    return {
+        "random": (rng.standard_normal(n), rng.standard_normal(n - 1)),
+        "toeplitz_1_2_1": (2.0 * np.ones(n), np.ones(n - 1)),
+        "wilkinson": (np.abs(np.arange(n) - m).astype(float), np.ones(n - 1)),
+        "glued_wilkinson": (dg, eg),
+        "clustered": (np.ones(n), 1e-9 * rng.standard_normal(n - 1)),
+        "graded": (10.0 ** (-np.arange(n) * 12.0 / n), 10.0 ** (-np.arange(1, n) * 12.0 / n)),
+        "zero_couplings": (rng.standard_normal(n), ez),
+        "clement": (np.zeros(n), np.sqrt(k * (n - k)) * 1e3),
+        "zero_matrix": (np.zeros(n), np.zeros(n - 1)),
+        "negative_couplings": (rng.standard_normal(n), -np.abs(rng.standard_normal(n - 1))),
+    }
+
+
+@pytest.mark.parametrize("n", [100, 129, 300, 1000, 2049])
+def test_tridiagonal_divide_and_conquer_on_the_device(ctx, n):
+    """chase_hip_stedc (secular equation, Gu-Eisenstat vectors and merge products on the GPU) on the matrices that break naive
+    divide & conquer: residual, orthogonality and eigenvalues within a small multiple of n eps ||T|| (the reference's RR test
+    allows 100 eps on well-separated spectra, tests/linalg/internal/cpu/rayleighRitz.cpp)."""
+    from chase_amd.capi import lib, check
+    rng = np.random.default_rng(5 + n)
+    for name, (d, e) in _tridiag_cases(n, rng).items():
+        nn = len(d)
+        w = np.zeros(nn)
+        dZ = ctx.empty((nn, nn), np.float64)
+        dd, ee = np.ascontiguousarray(d, dtype=np.float64), np.ascontiguousarray(e, dtype=np.float64)
+        check(lib.chase_hip_stedc(ctx.h, nn, dd.ctypes.data, ee.ctypes.data, w.ctypes.data, dZ.ptr, nn), "stedc")
+        Z = dZ.download()
+        dZ.free()
+        T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+        nrm = max(np.max(np.abs(d)), np.max(np.abs(e)), 1e-300)
+        assert np.all(np.diff(w) >= 0), name
+        assert np.max(np.abs(T @ Z - Z * w[None, :])) <= 10 * nn * EPS * nrm, (name, np.max(np.abs(T @ Z - Z * w[None, :])) / (nn * EPS * nrm))
+        assert np.max(np.abs(Z.T @ Z - np.eye(nn))) <= 10 * nn * EPS, (name, np.max(np.abs(Z.T @ Z - np.eye(nn))) / (nn * EPS))
+        assert np.max(np.abs(w - np.linalg.eigvalsh(T))) <= 10 * nn * EPS * nrm, name
