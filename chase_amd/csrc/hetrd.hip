@@ -557,9 +557,15 @@ extern "C" int chase_hip_heevd_gpu(chase_hip_ctx* c, int cplx_, int n, void* A_,
         static const int dc_min = [] { const char* e = getenv("CHASE_HIP_STEDC_GPU_MIN"); return e ? atoi(e) : 512; }();
         auto t1 = std::chrono::steady_clock::now();
         int r2;
-        if (!use_mrrr && dc_min > 0 && n >= dc_min) {
+        bool on_device = !use_mrrr && dc_min > 0 && n >= dc_min;
+        if (on_device) {
             r2 = stedc_gpu(c, n, hd.data(), hee.data(), w_host, Zr, n);
-        } else {
+            if (r2) {                                       // never observed; the host solver is the safety net, loudly
+                fprintf(stderr, "chase_hip: device divide & conquer failed (%s); falling back to the host solver\n", chase_hip_last_error());
+                on_device = false;
+            }
+        }
+        if (!on_device) {
             hz.resize((size_t)n * n);
             r2 = use_mrrr ? host_stemr(n, hd.data(), hee.data(), w_host, hz.data(), n)
                           : host_stedc(n, hd.data(), hee.data(), w_host, hz.data(), n);

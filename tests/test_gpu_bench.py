@@ -32,6 +32,7 @@ def check_common(d, n_gpus, steps, warmup):
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
     assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert d["converged"] is True and d["spectrum_check"]["ok"] is True
+    assert 0.0 < d["max_resid_recomputed"] < 1e-8                                            # independent check, fresh four-product H V
     assert len(d["timed"]["iterations"]) == steps
     assert d["ms_per_step"] > 0 and d["value"] > 0
 
@@ -56,3 +57,23 @@ def test_multi_rank_entry_point_on_one_gpu():
     assert d["iterations_per_solve"] == 9
     p = d["comm_probe"]
     assert p["col_group_panel_allreduce"]["ranks"] == 2 and p["panel_gemm_alone_ms_rounds4"] > 0
+
+
+def test_rank_of_a_torchrun_launch_on_one_gpu():
+    """the driver's multi-GPU call: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` - bench.py is then one
+    of the ranks (RANK set by the launcher).  Two ranks sharing this box's one GPU through the host test transport (which
+    leaves the device visibility alone; on the multi-GPU node every rank binds its runtime to its own device first)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29723", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg2", "--steps", "4", "--warmup", "1",
+           "--no-cpu-baseline", "--no-probe"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CHASE_HIP_TRANSPORT="host"))
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                      # rank 0 only
+    d = json.loads(lines[-1])
+    check_common(d, 2, 4, 1)
+    assert d["config"]["grid"] == "2x1" and d["config"]["transport"] == "host"
+    assert d["max_resid_recomputed"] < 1e-8
+    audit = [l for l in p.stderr.splitlines() if "device bus id" in l]
+    assert len(audit) == 2 and all("ncclCommCount" in l for l in audit)
