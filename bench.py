@@ -528,8 +528,18 @@ def main():
     if launched and world > 1 and "CHASE_HIP_BOUND_DEVICE" not in os.environ:
         # started by torch.distributed.run (the driver's multi-GPU call): nothing in this process has touched HIP yet
         # (numpy only), so the binding can still be made here, in place
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         bind_one_device(os.environ, int(os.environ.get("LOCAL_RANK", os.environ["RANK"])))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # stdout carries the ONE JSON line and nothing else: whatever libraries write to file descriptor 1 on the way (gloo's
+    # connection notes, RCCL's banner) is sent to stderr, the line goes to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(out):
+        if out is not None:
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
     if world > 1 or args.dist or args.workload in PSEUDO_WORKLOADS:
         if not launched:
             # grid Impl on a 1x1 grid (communicator-free) when started directly on one GPU
@@ -539,12 +549,9 @@ def main():
                 port = so.getsockname()[1]
             os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         from chase_amd.dist_bench import run_distributed
-        out = run_distributed(args)
-        if out is not None:
-            print(json.dumps(out), flush=True)
+        emit(run_distributed(args))
         return
-    out = run_single(args)
-    print(json.dumps(out), flush=True)
+    emit(run_single(args))
 
 
 if __name__ == "__main__":
