@@ -42,6 +42,13 @@ def scenario_hemm_kat(ctx, grid, comm):
     v = s.local_V()
     assert np.all(v[:, :2] == 806.0), v[:, :2]
     assert np.all(v[:, 2:] == 2.0)
+    # the product + column -> row redistribution pair of the reference's second known answer (nccl/hemm.cpp:227-367: H == 1,
+    # V == 2 -> H V == 20 on every row, the redistributed V == 2), through the path that uses both - the independent residual
+    # check: || H v - lambda v || = |20 - 2 lambda| sqrt(10), exact in floating point
+    s.upload_local_V(np.full((s.m_loc, 4), 2.0))
+    s.initVecs(False)
+    r = s.recompute_residuals(4, np.array([0.0, 10.0, 2.5, -1.0]))
+    assert np.array_equal(r, np.sqrt(10.0 * np.array([20.0, 0.0, 15.0, 22.0]) ** 2)), r
     s.close()
     # tests/linalg/internal/mpi/shiftDiagonal.cpp:31-77: identity (10 x 10) shifted by -5 -> -4 on the diagonal of the
     # shards that own diagonal entries, exact zeros everywhere else; block layout and block-cyclic nb = 3
