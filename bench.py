@@ -390,6 +390,12 @@ def run_single(args):
         # reference arithmetic (four real products per complex product, the reference's zgemm) on the same launch shape
         out["roofline_4m"] = fullwidth_probe(s, ctx, N, cplx, nevex, three_m=False)
         out["roofline_3m_fullwidth"] = fullwidth_probe(s, ctx, N, cplx, nevex, three_m=True)
+    # what THIS device's matrix pipe sustains in a bare register-resident MFMA loop right after the sustained load above
+    # (context for `frac`: the boxes of the pool differ by a few per cent on the 3M kernel; never its denominator)
+    try:
+        out["roofline"]["bare_mfma_loop_tflops_this_device"] = ctx.mfma_f64_peak()
+    except Exception as e:  # informative only
+        out["roofline"]["bare_mfma_loop_tflops_this_device"] = None
     s.close()
     del dH
     ctx.close()
