@@ -191,6 +191,7 @@ class StepTimer:
         self.solve_index = 0
         self.complete_solves = 0
         self._last = None
+        self.progress = os.environ.get("RANK", "0") == "0" and os.environ.get("CHASE_BENCH_QUIET") != "1"
 
     @property
     def running(self):
@@ -212,6 +213,9 @@ class StepTimer:
 
     def hook(self, it, filtered, locked, unconverged):
         self.boundary += 1
+        if self.progress:                      # one line per outer iteration on stderr: a long run is visibly alive
+            print(f"bench: solve {self.solve_index} iteration {it}: {filtered} vectors filtered, {locked} locked, "
+                  f"{unconverged} unconverged" + (" [timed]" if self.running else ""), file=sys.stderr, flush=True)
         if self.running:
             self.filtered_timed += filtered
             now = time.perf_counter()          # host clock only: informative per-iteration split, not the timed bracket
