@@ -379,9 +379,9 @@ int stedc_gpu(chase_hip_ctx* c, int n, const double* d_in, const double* e_in, d
                     if (e3) return hip_fail((hipError_t)e3, "stedc_gpu deflated copy");
                 }
             }
+            if (any) DCHK(hipMemcpyAsync(h_dl.data(), lam, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+            DCHK(hipStreamSynchronize(st));                          // also: the host lists above are reused by the next level
             if (any) {
-                DCHK(hipMemcpyAsync(h_dl.data(), lam, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
-                DCHK(hipStreamSynchronize(st));
                 for (const Merge& m : lv)
                     for (int t = 0; t < m.k; ++t) {
                         if (!std::isfinite(h_dl[m.o + t])) return set_error(CHASE_HIP_ENOTCONV, "stedc_gpu: secular equation produced a non-finite root");
