@@ -47,14 +47,16 @@ int main(int argc, char** argv)
     double _Complex* H = calloc((size_t)m * n, sizeof *H);
     double _Complex* V = calloc((size_t)m * (nev + nex), sizeof *V);
     double* lambda = calloc((size_t)(nev + nex), sizeof *lambda);
+    /* like the reference's example (examples/4_interface/4_c_dist_chase.c): the block is handed to init first and filled
+     * afterwards - the interface keeps the pointer and reads the block at every pzchase_ call */
+    pzchase_init_(&N, &nev, &nex, &m, &n, H, &m, V, lambda, &dims[0], &dims[1], &major, &comm, &init);
+    if (!init) { fprintf(stderr, "rank %d: pzchase_init_ failed\n", rank); MPI_Abort(comm, 2); }
     for (int j = 0; j < n; ++j)
         for (int i = 0; i < m; ++i) {
             const int gi = r0 + i, gj = c0 + j;
             if (gi == gj + 1) H[i + (size_t)j * m] = sqrt((double)gj * (double)(N + 1 - gj));
             if (gj == gi + 1) H[i + (size_t)j * m] = sqrt((double)gi * (double)(N + 1 - gi));
         }
-    pzchase_init_(&N, &nev, &nex, &m, &n, H, &m, V, lambda, &dims[0], &dims[1], &major, &comm, &init);
-    if (!init) { fprintf(stderr, "rank %d: pzchase_init_ failed\n", rank); MPI_Abort(comm, 2); }
     pzchase_(&deg, &tol, &mode, &opt, &qr);
     /* analytic spectrum and the residual of the first pairs: r = H v - lambda v needs the whole vector -> gather it */
     double worst = 0.0;
