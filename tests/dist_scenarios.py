@@ -210,7 +210,7 @@ def scenario_reference_units(ctx, grid, comm, cplx, mb):
     note("reference Lanczos ok")
 
 
-def scenario_solve(ctx, grid, comm, N, nev, nex, cplx, mb, deg):
+def scenario_solve(ctx, grid, comm, N, nev, nex, cplx, mb, deg, same_iterations=True):
     """Full distributed solve vs the serial oracle (tests/chase_distributed_solve.cpp:38-115,209-284)."""
     rank, world = comm.rank, comm.world
     H = O.clement(N, cplx)
@@ -238,7 +238,13 @@ def scenario_solve(ctx, grid, comm, N, nev, nex, cplx, mb, deg):
     r_dev = s.recompute_residuals(nev)               # mpi/residuals.hpp on the grid, from a fresh four-product H V
     assert np.max(np.abs(r_dev - r_host)) <= 1e-12 * np.abs(H).max() and np.max(r_dev) < 1e-8
     assert O.orthogonality(V) < 1e-9
-    assert abs(st["iterations"] - so["iterations"]) <= 2, (st["iterations"], so["iterations"])
+    # The iteration count is compared with the SEQUENTIAL oracle only where the two references agree closely: pChASECPU::QR copies
+    # the orthonormalised block into V2 (pchase_cpu.hpp:863-866), ChASECPU::QR does not (chase_cpu.hpp:764-772), and LanczosDos
+    # then copies V2's columns idx..m-1 into the start block (chase_cpu.hpp:380, pchase_cpu.hpp:360) - a different (equally
+    # random) start space, which on tiny problems changes the filter bounds' history and with it the count (N = 301, nev = 20:
+    # 4 against 10 iterations from the same random block; the grid Impl's operators are bitwise those of the sequential one)
+    if same_iterations:
+        assert abs(st["iterations"] - so["iterations"]) <= 2, (st["iterations"], so["iterations"])
     # every rank holds identical Ritz values (control-flow agreement)
     allv = comm.all_gather_object(lam)
     assert all(np.array_equal(allv[0], a) for a in allv)

@@ -105,3 +105,15 @@ def test_distributed_c_entry_points(nranks, typ, mb):
 @pytest.mark.parametrize("nranks", [4, 6, 8])
 def test_grid_sendrecv_and_exact_agree_max(nranks):
     run(nranks, S.scenario_p2p)
+
+
+@pytest.mark.parametrize("nprow,npcol,N,nev,nex,cplx,mb", [
+    (3, 1, 301, 20, 10, False, 7),        # odd grid, block size that divides nothing
+    (3, 2, 200, 60, 40, True, 0),         # half of the spectrum wanted, block layout with a short last block
+    (2, 2, 130, 12, 1, True, 1),          # one extra vector, block-cyclic with 1 x 1 blocks
+    (4, 1, 257, 30, 20, False, 64),       # last grid rows own a single partial block
+    (2, 1, 96, 40, 40, False, 0),         # search space = 5/6 of the matrix
+])
+def test_solve_on_awkward_grids_and_sizes(nprow, npcol, N, nev, nex, cplx, mb):
+    from rank_threads import run_ranks as run_grid
+    run_grid(nprow, npcol, S.scenario_solve, N, nev, nex, cplx, mb, 20, same_iterations=False)
