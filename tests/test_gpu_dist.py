@@ -117,3 +117,11 @@ def test_grid_sendrecv_and_exact_agree_max(nranks):
 def test_solve_on_awkward_grids_and_sizes(nprow, npcol, N, nev, nex, cplx, mb):
     from rank_threads import run_ranks as run_grid
     run_grid(nprow, npcol, S.scenario_solve, N, nev, nex, cplx, mb, 20, same_iterations=False)
+
+
+@pytest.mark.parametrize("nprow,npcol,mb", [(3, 1, 0), (3, 2, 0), (4, 1, 0), (3, 1, 16), (2, 2, 1), (4, 2, 8)])
+def test_pseudo_solve_on_awkward_grids(nprow, npcol, mb):
+    """the K-conjugation partner rows (g + N/2) mod N land on other ranks in patterns the 2 x 2 / 4 x 2 cases do not produce"""
+    from rank_threads import run_ranks as run_grid
+    run_grid(nprow, npcol, S.scenario_pseudo_solve, mb)
+    run_grid(nprow, npcol, S.scenario_pseudo_ops, mb)
