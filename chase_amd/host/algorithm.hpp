@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <limits>
 #include <numeric>
+#include <stdexcept>
 #include <string>
 #include <vector>
 #include "interface.hpp"
@@ -63,6 +64,13 @@ public:
     using R = Base<T>;
     using clock = std::chrono::steady_clock;
     static double since(clock::time_point t0) { return std::chrono::duration<double>(clock::now() - t0).count(); }
+    // The reference sizes its Lanczos runs as min(nev+nex, N/2, lanczosIter) made even and asserts m >= 1
+    // (algorithm/algorithm.inc:1073,1438-1442): a problem too small for two steps is outside its domain (undefined behaviour
+    // in a release build there) - refused here with a message instead
+    static void require_lanczos_steps(std::size_t m)
+    {
+        if (m < 2) throw std::invalid_argument("chase: problem too small - the Lanczos bounds need min(nev+nex, N/2) >= 2");
+    }
 
     // growth factor of the Chebyshev polynomial outside [-1, 1]
     static R rho_of(R t)
@@ -437,6 +445,7 @@ public:
         t0 = clock::now();
         std::size_t lanczos_iter = std::min(nevex, std::min(N / 2, cfg.GetLanczosIter()));
         if (lanczos_iter % 2 != 0) { cfg.SetLanczosIter(lanczos_iter - 1); lanczos_iter = cfg.GetLanczosIter(); }
+        require_lanczos_steps(lanczos_iter);
         R upperb = 0;
         lanczos_for_H2(k, (int)N, (int)cfg.GetNumLanczos(), (int)lanczos_iter, (int)nevex, &upperb, ritzv_all);
         st->lanczos_vecs = lanczos_iter * cfg.GetNumLanczos();
@@ -574,6 +583,11 @@ public:
             cfg.SetLanczosIter(lanczos_iter - 1);
             lanczos_iter = cfg.GetLanczosIter();
         }
+        require_lanczos_steps(lanczos_iter);
+        // the numLanczos start vectors of the random-start runs are the first numLanczos columns of the block
+        // (linalg/internal/cpu/lanczos.hpp:46-209 copies them without asking how many there are)
+        if (random && nevex < cfg.GetNumLanczos())
+            throw std::invalid_argument("chase: nev + nex must be at least numLanczos (the Lanczos runs start from that many columns)");
         R upperb = 0;
         if (tr) tr->add("Lanczos %zu %zu", lanczos_iter, cfg.GetNumLanczos());
         lanczos(k, (int)N, (int)cfg.GetNumLanczos(), (int)lanczos_iter, (int)nevex, &upperb, random,
