@@ -12,6 +12,7 @@ calls chase_amd.dist.Grid needs (allreduce / bcast / sendrecv on float64 views).
 torch.distributed for the few tests that still run ranks as processes."""
 import queue
 import threading
+import time
 import traceback
 
 import numpy as np
@@ -144,7 +145,7 @@ def run_threads(nprow, npcol, body):
             body(comm)
             comm.barrier()
         except BaseException as e:  # noqa: BLE001 - reported to the caller below
-            errors[rank] = (e, traceback.format_exc())
+            errors[rank] = (e, traceback.format_exc(), time.monotonic())
             world.abort()
 
     threads = [threading.Thread(target=wrapped, args=(r,), name=f"rank{r}", daemon=True) for r in range(world.n)]
@@ -153,12 +154,12 @@ def run_threads(nprow, npcol, body):
     for t in threads:
         t.join(TIMEOUT + 60)
     alive = [t.name for t in threads if t.is_alive()]
-    # the first REAL failure (a rank that only saw the others' broken barrier is a consequence, not a cause)
-    failed = [(r, e) for r, e in enumerate(errors) if e]
-    real = [(r, e) for r, e in failed if "BrokenBarrierError" not in e[1] and "peer never sent" not in e[1]]
+    # the FIRST failure in time is the cause; the ranks that then found their barriers broken (directly, or as a failed
+    # transport callback inside the library) are consequences
+    failed = sorted(((e[2], r, e) for r, e in enumerate(errors) if e), key=lambda t: t[0])
     if failed:
-        r, (e, tb) = (real or failed)[0]
-        raise AssertionError(f"rank {r} of the {nprow}x{npcol} grid failed:\n{tb}") from e
+        _, r, (e, tb, _) = failed[0]
+        raise AssertionError(f"rank {r} of the {nprow}x{npcol} grid failed first:\n{tb}") from e
     assert not alive, f"ranks still running after the timeout: {alive}"
 
 
