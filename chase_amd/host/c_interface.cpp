@@ -94,7 +94,7 @@ void dchase_get_eigenpairs_(double* LEigsV, int* ld, double* ritzv) { if (ld) ge
 void dchase_finalize_(int* flag)
 {
     g_d.clear();
-    *flag = 1;
+    if (flag) *flag = 0;                     // ChASE_SEQ<...>::Finalize() returns 0 (chase_c_interface.cpp:320-368)
 }
 
 void zchase_init_(int* N, int* nev, int* nex, void* H, int* ldh, void* V, double* ritzv, int* init)
@@ -132,7 +132,7 @@ void zchase_get_eigenpairs_(void* LEigsV, int* ld, double* ritzv)
 void zchase_finalize_(int* flag)
 {
     g_z.clear(); g_zp.clear();
-    *flag = 1;
+    if (flag) *flag = 0;
 }
 void chase_enable_sym_check_(int* flag) { if (flag) g_sym_check = *flag != 0; }
 

@@ -220,9 +220,9 @@ def test_c_interface_shim(ctx, cplx):
     solve(ci(16), C.byref(C.c_double(1e-10)), C.c_char_p(b"A"), C.c_char_p(b"S"), C.c_char_p(b"C"))
     assert np.max(O.residuals(H2, lam[:nev].copy(), V[:, :nev])) < RESID_TOL
     assert np.max(np.abs(lam[:nev] - lam1)) < 1e-3
-    flag = C.c_int(0)
+    flag = C.c_int(7)
     getattr(lib, pre + "chase_finalize_")(C.byref(flag))
-    assert flag.value == 1
+    assert flag.value == 0                               # ChASE_SEQ<...>::Finalize() returns 0 (chase_c_interface.cpp:320-368)
 
 
 def test_device_generated_complex_n8192_full_size_properties(ctx):
@@ -301,9 +301,9 @@ def test_c_interface_internal_storage_and_get_eigenpairs(ctx):
     lam = np.zeros(nev)
     lib.dchase_get_eigenpairs_(C.c_void_p(V.ctypes.data), ci(ld), C.c_void_p(lam.ctypes.data))
     assert np.max(O.residuals(H, lam, V[:N, :])) < RESID_TOL and np.all(V[N:, :] == 0)
-    flag = C.c_int(0)
+    flag = C.c_int(7)
     lib.dchase_finalize_(C.byref(flag))
-    assert flag.value == 1
+    assert flag.value == 0
 
 
 def test_c_interface_unified_setters_and_queries(ctx):
@@ -346,9 +346,9 @@ def test_c_interface_unified_setters_and_queries(ctx):
     lib.dchase_(ci(10), C.byref(C.c_double(1e-10)), C.c_char_p(b"R"), C.c_char_p(b"S"), C.c_char_p(b"C"))
     assert np.max(O.residuals(H, lam[:nev].copy(), V[:, :nev])) < RESID_TOL
     lib.chase_print_config_()
-    flag = C.c_int(0)
+    flag = C.c_int(7)
     lib.dchase_finalize_(C.byref(flag))
-    assert flag.value == 1 and not lib.chase_hip_cshim_seq_solver(0)
+    assert flag.value == 0 and not lib.chase_hip_cshim_seq_solver(0)
 
 
 def test_c_interface_pseudo_hermitian(ctx):
@@ -378,9 +378,9 @@ def test_c_interface_pseudo_hermitian(ctx):
     lo = np.zeros(nev)
     lib.zchase_get_eigenpairs_(C.c_void_p(out.ctypes.data), ci(N), C.c_void_p(lo.ctypes.data))
     assert np.array_equal(out, V[:, :nev]) and np.array_equal(lo, lam[:nev])
-    flag = C.c_int(0)
+    flag = C.c_int(7)
     lib.zchase_finalize_(C.byref(flag))
-    assert flag.value == 1
+    assert flag.value == 0
 
 
 def test_plain_c_caller_of_the_c_interface(tmp_path):
@@ -562,3 +562,43 @@ def test_problems_too_small_for_the_lanczos_bounds_are_refused(ctx, N, nev, nex)
     with pytest.raises(ChaseHipError, match="too small|at least numLanczos"):
         s.solve()
     s.close()
+
+
+def test_c_interface_misuse_and_bad_input_are_harmless(ctx):
+    """calls without an initialised solver, bad sizes, double init / finalize, a NaN in the matrix: error flags and messages,
+    never a crash or a hang (the reference's entry points are void functions on static solver objects,
+    interface/chase_c_interface.cpp:2204-2400)"""
+    import ctypes as C
+    from chase_amd.capi import lib
+    I = lambda v: C.byref(C.c_int(v))
+    deg, tol = C.c_int(20), C.c_double(1e-10)
+
+    def solve(fn):
+        getattr(lib, fn)(C.byref(deg), C.byref(tol), C.c_char_p(b"R"), C.c_char_p(b"S"), C.c_char_p(b"C"))
+
+    flag = C.c_int(9)
+    for fn in ("dchase_", "zchase_", "pdchase_", "pzchase_"):              # nothing initialised: no-ops
+        solve(fn)
+    lib.dchase_finalize_(C.byref(flag)); lib.zchase_finalize_(C.byref(flag)); lib.pdchase_finalize_(C.byref(flag))
+    N, nev, nex = 120, 10, 6
+    H = O.clement(N, False)
+    V = np.zeros((N, nev + nex), order="F"); ritzv = np.zeros(nev + nex); init = C.c_int(1)
+    args = lambda n2, ldh, Hm: (I(N), I(nev), I(n2), C.c_void_p(Hm.ctypes.data), I(ldh), C.c_void_p(V.ctypes.data),
+                                C.c_void_p(ritzv.ctypes.data), C.byref(init))
+    lib.dchase_init_(*args(N, N, H))
+    assert init.value == 0 and b"nev+nex" in lib.chase_hip_last_error()
+    lib.dchase_init_(*args(nex, N - 1, H))
+    assert init.value == 0 and b"leading dimension" in lib.chase_hip_last_error()
+    for _ in range(2):                                                      # a second init replaces the first solver
+        lib.dchase_init_(*args(nex, N, H))
+        assert init.value == 1
+    solve("dchase_")
+    assert abs(ritzv[0] + 120.0) < 1e-5
+    lib.dchase_finalize_(C.byref(flag)); lib.dchase_finalize_(C.byref(flag))
+    assert flag.value == 0
+    solve("dchase_")                                                        # finalised: a no-op again
+    Hn = H.copy(); Hn[3, 3] = np.nan
+    lib.dchase_init_(*args(nex, N, Hn))
+    solve("dchase_")                                                        # returns; the failure is on record
+    assert lib.chase_hip_last_error() != b""
+    lib.dchase_finalize_(C.byref(flag))
