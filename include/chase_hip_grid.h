@@ -4,9 +4,10 @@
  * typed wrappers of grid/nccl_utils.hpp:200-278.  Rank -> coordinates is the reference's column-major grid ordering
  * (rank = row + col * nprow, grid/mpiGrid2D.hpp:402-446).  Two transports:
  *   - RCCL over xGMI (production): ncclAllReduce / ncclBroadcast of doubles on a dedicated HIP stream;
- *   - host callbacks (test plumbing): the payload is staged through pinned host memory and handed to a callback
- *     (tests supply torch.distributed/gloo), which lets N ranks share ONE GPU so that the distributed code path is
- *     exercised on a single-GPU box.
+ *   - host callbacks (test plumbing): the payload is staged through pinned host memory and handed to a callback (the tests
+ *     supply one that meets the other ranks' callbacks inside the process - ranks as threads - or torch.distributed/gloo -
+ *     ranks as processes), which lets N ranks share ONE GPU so that the distributed code path is exercised on a
+ *     single-GPU box.  A rank is whatever calls the collectives in the same order as its peers: a process or a thread.
  * Groups: CHASE_HIP_ROW = ranks sharing a grid row (size npcol, the reference's row_comm),
  *         CHASE_HIP_COL = ranks sharing a grid column (size nprow, the reference's col_comm).
  * Data layout helpers implement the reference's block rule (linalg/distMatrix/distMatrix.hpp:1992-2052) and numroc
