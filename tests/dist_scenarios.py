@@ -251,6 +251,30 @@ def scenario_solve(ctx, grid, comm, N, nev, nex, cplx, mb, deg, same_iterations=
     s.close()
 
 
+def scenario_solve_counts(ctx, grid, comm, N, nev, nex, cplx, mb, deg):
+    """The grid Impl from the reference's own start vectors (mt19937(1337 + grid row) per block of local rows,
+    pchase_cpu.hpp:272-283) against the oracle in its pChASECPU form (same start block, V2 refreshed by QR, Swap on both
+    blocks): the driver must take the SAME path - iterations and filtered vectors equal, not just close."""
+    H = O.clement(N, cplx)
+    rl, cl = cd.Layout(N, mb, grid.nprow), cd.Layout(N, mb, grid.npcol)
+    dH = ctx.array(cd.local_block_of(H, rl, cl, grid.myrow, grid.mycol))
+    s = cd.DistSolver(ctx, grid, dH, N, nev, nex, cplx, mb, mb)
+    s.set(deg=deg)                                   # host generator: the reference's start vectors
+    st = s.solve()
+    lam = s.ritzv[:nev].copy()
+
+    def oracle_solve():
+        k = O.OracleCPU(H, nev, nex, grid_rows=[rl.globals_of(i) for i in range(grid.nprow)])
+        k.config.deg = deg
+        return k, O.solve(k)
+    k, so = comm.once(("solve_counts", N, nev, nex, cplx, mb, deg, grid.nprow), oracle_solve)
+    assert np.max(np.abs(lam - k.ritzv[:nev])) < 1e-8
+    assert np.max(s.recompute_residuals(nev)) < 1e-8
+    assert (st["iterations"], st["filtered_vecs"]) == (so["iterations"], so["filtered_vecs"]), \
+        (st["iterations"], st["filtered_vecs"], so["iterations"], so["filtered_vecs"])
+    s.close()
+
+
 def scenario_symcheck(ctx, grid, comm, cplx, mb):
     """Distributed randomized Hermiticity test (mpi/symOrHerm.hpp:46-96): true on a Hermitian matrix, false on every
     rank once a single off-diagonal entry is changed anywhere."""

@@ -125,3 +125,15 @@ def test_pseudo_solve_on_awkward_grids(nprow, npcol, mb):
     from rank_threads import run_ranks as run_grid
     run_grid(nprow, npcol, S.scenario_pseudo_solve, mb)
     run_grid(nprow, npcol, S.scenario_pseudo_ops, mb)
+
+
+@pytest.mark.parametrize("nprow,npcol,N,nev,nex,cplx,mb", [
+    (2, 2, 256, 24, 16, True, 0), (2, 2, 1001, 100, 60, False, 64), (3, 1, 301, 20, 10, False, 7), (3, 2, 200, 60, 40, True, 0),
+    (4, 1, 257, 30, 20, False, 64), (4, 2, 600, 40, 24, True, 16), (2, 1, 301, 20, 10, False, 0), (1, 1, 301, 20, 10, False, 0),
+])
+def test_grid_solver_takes_the_reference_distributed_path_count_for_count(nprow, npcol, N, nev, nex, cplx, mb):
+    """iterations and filtered vectors EQUAL to the oracle following pChASECPU (start vectors per grid row, V2 refreshed by QR):
+    the two reference Impls differ there, and on small problems the counts differ with them (3 x 1, N = 301: 10 iterations
+    against the sequential Impl's 4) - the grid Impl must follow the distributed one"""
+    from rank_threads import run_ranks as run_grid
+    run_grid(nprow, npcol, S.scenario_solve_counts, N, nev, nex, cplx, mb, 20)

@@ -201,6 +201,21 @@ def test_oracle_reproduces_runs_of_the_actual_reference(N, cplx, nev, nex, iters
     assert np.max(k.resid[:nev]) <= 1e-10
 
 
+def test_oracle_in_its_distributed_form_reproduces_the_reference_example_run():
+    """examples/1_hello_world measured with the actual reference binary (BASELINE.md cross-check table): pChASECPU, unperturbed
+    complex Clement N = 1200, nev = 80, nex = 60, block-cyclic nb = 64 on a 2 x 2 grid -> 6 iterations, 13 310 filtered vectors.
+    The oracle follows pChASECPU where the two reference Impls differ for the driver (start vectors from mt19937(1337 + grid
+    row) per block of local rows, V2 refreshed by QR, Swap on both blocks); in its ChASECPU form the same problem takes 5
+    iterations / 12 664 vectors (test above), like the reference's sequential binary."""
+    from chase_amd import dist as cd
+    N, nev, nex, nb = 1200, 80, 60, 64
+    rl = cd.Layout(N, nb, 2)
+    k = O.OracleCPU(O.clement(N, True, perturb=0), nev, nex, grid_rows=[rl.globals_of(i) for i in range(2)])
+    so = O.solve(k)
+    assert (so["iterations"], so["filtered_vecs"]) == (6, 13310)
+    assert np.max(np.abs(k.ritzv[:nev] - (-N + 2.0 * np.arange(nev)))) < 1e-8
+
+
 @pytest.mark.parametrize("tag,N", [("cdouble_tiny_random_BSE", 10), ("cdouble_random_BSE", 200)])
 def test_flip_lower_half_gives_the_fixture_SH_spectrum(tag, N):
     """S H (lower half of the rows negated, flipLowerHalfMatrixSign) is Hermitian positive definite with the spectrum the
