@@ -493,6 +493,30 @@ def scenario_pseudo_solve(ctx, grid, comm, mb):
     s.close()
 
 
+def scenario_pseudo_solve_counts(ctx, grid, comm, mb):
+    """chase::Solve_pseudo on the grid from the reference's own start vectors against the oracle in its pChASECPU form:
+    iterations and filtered vectors equal"""
+    H, pos = bse_fixture()
+    N, nev, nex = 200, 20, 20
+    rl, cl = cd.Layout(N, mb, grid.nprow), cd.Layout(N, mb, grid.npcol)
+    dH = ctx.array(cd.local_block_of(H, rl, cl, grid.myrow, grid.mycol))
+    s = cd.DistPseudoSolver(ctx, grid, dH, N, nev, nex, True, mb, mb)
+    s.set(tol=1e-10, deg=20, opt=1, maxiter=25, numlanczos=10, lanczositer=50)
+    st = s.solve()
+    lam = s.ritzv[:nev].copy()
+
+    def oracle_solve():
+        k = O.OraclePseudoCPU(H, nev, nex, grid_rows=[rl.globals_of(i) for i in range(grid.nprow)])
+        k.config.num_lanczos = 10; k.config.lanczos_iter = 50
+        return k, O.solve_pseudo(k)
+    k, so = comm.once(("pseudo_counts", mb, grid.nprow), oracle_solve)
+    assert np.max(np.abs(lam - k.ritzv[:nev])) <= 1e-9
+    assert np.max(s.recompute_residuals(nev)) <= 1e-9
+    assert (st["iterations"], st["filtered_vecs"]) == (so["iterations"], so["filtered_vecs"]), \
+        (st["iterations"], st["filtered_vecs"], so["iterations"], so["filtered_vecs"])
+    s.close()
+
+
 def scenario_cshim(ctx, grid, comm, cplx, mb):
     """The distributed C entry points (interface/chase_c_interface.h:61-65,95-99,126-128,149,177-195) in their grid-handle
     form: p?chase_init[_blockcyclic]_hip_ with the caller's HOST blocks, p?chase_, p?chase_get_eigenpairs_,

@@ -137,3 +137,9 @@ def test_grid_solver_takes_the_reference_distributed_path_count_for_count(nprow,
     against the sequential Impl's 4) - the grid Impl must follow the distributed one"""
     from rank_threads import run_ranks as run_grid
     run_grid(nprow, npcol, S.scenario_solve_counts, N, nev, nex, cplx, mb, 20)
+
+
+@pytest.mark.parametrize("nprow,npcol,mb", [(2, 2, 0), (4, 2, 0), (3, 1, 0), (2, 1, 16), (1, 1, 0)])
+def test_pseudo_grid_solver_takes_the_reference_distributed_path_count_for_count(nprow, npcol, mb):
+    from rank_threads import run_ranks as run_grid
+    run_grid(nprow, npcol, S.scenario_pseudo_solve_counts, mb)
