@@ -468,8 +468,25 @@ int chase_hip_pseudo_rr_small(chase_hip_ctx* c, int cplx, int n, void* A_dev, vo
     HIPCHK(hipMemcpyAsync(hA, A_dev, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(hM, M_dev, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    const int rc = host_pseudo_rr(cplx != 0, n, hA, hM, ritzv_host);
-    if (rc) return rc;
+    // large cores (config 5: 2 (nev + nex) = 640): the Hermitian eigenproblem in the middle goes through chase_hip_heevd, i.e.
+    // tridiagonalisation / divide & conquer / back-transformation on the device; potrf and the three trsm stay on the host
+    static const int gpu_min = [] { const char* e = getenv("CHASE_HIP_HEEVD_GPU_MIN"); return e ? atoi(e) : 384; }();
+    if (gpu_min > 0 && n >= gpu_min) {
+        int rc = host_pseudo_rr_pre(cplx != 0, n, hA, hM);
+        if (rc) return rc;
+        std::vector<double> L(hA, hA + bytes / sizeof(double));        // the eigensolver may reuse the staging buffer
+        HIPCHK(hipMemcpyAsync(M_dev, hM, bytes, hipMemcpyHostToDevice, c->stream));
+        RCCHK(chase_hip_heevd(c, cplx, n, M_dev, n, ritzv_host));
+        RCCHK(c->ensure_hstage(bytes));
+        hM = (double*)c->hstage;
+        HIPCHK(hipMemcpyAsync(hM, M_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        rc = host_pseudo_rr_post(cplx != 0, n, L.data(), hM, ritzv_host);
+        if (rc) return rc;
+    } else {
+        const int rc = host_pseudo_rr(cplx != 0, n, hA, hM, ritzv_host);
+        if (rc) return rc;
+    }
     HIPCHK(hipMemcpyAsync(M_dev, hM, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;

@@ -181,7 +181,10 @@ int host_heevd(bool cplx, int n, double* A, int lda, double* w)
 // linalg/internal/cpu/rayleighRitz.hpp:316-383):  A = Q^H S H Q (Hermitian positive definite), M = Q^H S Q.
 //   A = L L^H;  M <- -L^-1 M L^-H;  heevd(M) -> (w, Z);  w <- -w;  Z <- L^-H Z;  ritz = 1 / w;  normalise Z[:, :n/2]
 // On return M holds Z and w the Ritz values.  Returns potrf info (> 0) if A is not positive definite.
-int host_pseudo_rr(bool cplx, int n, double* A, double* M, double* w)
+// The dense core of the pseudo-Hermitian Rayleigh-Ritz in two halves around the eigensolver (cpu/rayleighRitz.hpp:330-392):
+//   pre :  A = L L^H,  M <- -(L^-1 M L^-H)                                   (returns the potrf info if A is not positive definite)
+//   post:  Z <- L^-H Z,  w <- 1 / (-w),  first n/2 columns normalised        (Z = eigenvectors of the matrix pre left in M)
+int host_pseudo_rr_pre(bool cplx, int n, double* A, double* M)
 {
     if (n <= 0) return 0;
     int rc = lapack_bind(nullptr);
@@ -198,14 +201,22 @@ int host_pseudo_rr(bool cplx, int n, double* A, double* M, double* w)
         builtin_trsm_lower(cplx, 'L', 'N', n, A, n, M, n);
         builtin_trsm_lower(cplx, 'R', 'C', n, A, n, M, n);
     } else {
-    potrf("L", &n, A, &n, &info);
-    if (info != 0) return info > 0 ? info : set_error(CHASE_HIP_EINVAL, "host potrf: illegal argument");
-    trsm("L", "L", "N", "N", &n, &n, one, A, &n, M, &n);
-    trsm("R", "L", "C", "N", &n, &n, one, A, &n, M, &n);
+        potrf("L", &n, A, &n, &info);
+        if (info != 0) return info > 0 ? info : set_error(CHASE_HIP_EINVAL, "host potrf: illegal argument");
+        trsm("L", "L", "N", "N", &n, &n, one, A, &n, M, &n);
+        trsm("R", "L", "C", "N", &n, &n, one, A, &n, M, &n);
     }
     for (size_t i = 0; i < (size_t)n * n * E; ++i) M[i] = -M[i];
-    rc = host_heevd(cplx, n, M, n, w);
-    if (rc) return rc;
+    return 0;
+}
+int host_pseudo_rr_post(bool cplx, int n, const double* A, double* M, double* w)
+{
+    if (n <= 0) return 0;
+    trsm_t trsm = cplx ? g_ztrsm : g_dtrsm;
+    potrf_t potrf = cplx ? g_zpotrf : g_dpotrf;
+    const bool own = g_builtin || !potrf || !trsm;
+    const int E = cplx ? 2 : 1;
+    const double one[2] = {1.0, 0.0};
     for (int i = 0; i < n; ++i) w[i] = -w[i];
     if (own) builtin_trsm_lower(cplx, 'L', 'C', n, A, n, M, n);
     else trsm("L", "L", "C", "N", &n, &n, one, A, &n, M, &n);
@@ -218,6 +229,14 @@ int host_pseudo_rr(bool cplx, int n, double* A, double* M, double* w)
         for (int i = 0; i < n * E; ++i) col[i] *= inv;
     }
     return 0;
+}
+int host_pseudo_rr(bool cplx, int n, double* A, double* M, double* w)
+{
+    int rc = host_pseudo_rr_pre(cplx, n, A, M);
+    if (rc) return rc;
+    rc = host_heevd(cplx, n, M, n, w);
+    if (rc) return rc;
+    return host_pseudo_rr_post(cplx, n, A, M, w);
 }
 
 // divide & conquer tridiagonal eigensolver (compz = 'I'): eigenvalues ascending in d (copied to w), eigenvectors in Z

@@ -15,5 +15,7 @@ int host_stemr(int n, double* d, double* e, double* w, double* Z, int ldz);
 int host_stedc(int n, double* d, double* e, double* w, double* Z, int ldz);   // divide & conquer, same contract
 // small dense core of the pseudo-Hermitian Rayleigh-Ritz (see host_lapack.cpp); A, M are n x n host, column-major
 int host_pseudo_rr(bool cplx, int n, double* A, double* M, double* w);
+int host_pseudo_rr_pre(bool cplx, int n, double* A, double* M);
+int host_pseudo_rr_post(bool cplx, int n, const double* A, double* M, double* w);
 void lapack_set_threads(int nthreads);
 }
