@@ -18,6 +18,10 @@ iterations are timed between two (device sync + barrier) brackets.  Everything a
             on full-width HEMMs, the CPU oracle on the host cores.
 `python bench.py --gpus N` with N > 1 starts its N ranks itself (one process per GPU, RCCL row/column all-reduces over
 xGMI on the reference's 2D grid, grid/mpiGrid2D.hpp); under torch.distributed.run (RANK set) it is one of the ranks.
+`--ranks threads` runs the N ranks as threads of ONE process (one thread per GPU).  A multi-GPU run proves its transport
+before it solves (bus bandwidth of a 256 MB all-reduce per communicator, `transport_proof` in the JSON line) and exits
+non-zero instead of printing a scaling number when RCCL is not on xGMI; with `--ranks auto` (default) the way the ranks
+hold their devices is settled by short-lived probe children BEFORE this process touches the GPU.
 """
 import argparse
 import json
@@ -174,15 +178,71 @@ def cpu_baseline(N, cplx, ncols, budget_s=25.0):
     return out
 
 
+class CpuBaselineJob:
+    """The CPU baseline as a CPU-only CHILD process started at the beginning of the run (it imports numpy / scipy and the
+    oracle, never HIP or torch) and joined before the timed region starts: its ~35 s run beside the untimed warm-up
+    iterations instead of serially after the GPU work (round-3 verdict: the bench's wall budget), and never beside a timed
+    one.  The child gets a clean environment (no profiler preload), so `rocprofv3 -- python bench.py` profiles one GPU
+    process."""
+
+    def __init__(self, N, cplx, ncols, budget_s):
+        env = {k: v for k, v in os.environ.items()
+               if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTRACER"))}
+        self.args = (N, cplx, ncols, budget_s)
+        self.out = tempfile.TemporaryFile(mode="w+")
+        self.err = tempfile.TemporaryFile(mode="w+")
+        self.t0 = time.perf_counter()
+        self.proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child",
+                                      f"{N},{int(bool(cplx))},{ncols},{budget_s}"], env=env, stdout=self.out, stderr=self.err)
+        self.waited_s = None
+
+    def join(self):
+        """blocks until the child is done; returns the seconds this call had to wait (0 when it finished during warm-up)"""
+        if self.waited_s is None:
+            t = time.perf_counter()
+            self.proc.wait()
+            self.waited_s = time.perf_counter() - t
+            self.total_s = time.perf_counter() - self.t0
+        return self.waited_s
+
+    def result(self):
+        self.join()
+        self.out.seek(0)
+        lines = [l for l in self.out.read().splitlines() if l.startswith("{") and l.endswith("}")]
+        if self.proc.returncode == 0 and lines:
+            rec = json.loads(lines[-1])
+            rec["ran"] = ("CPU-only child process started with the run, beside the untimed warm-up iterations of the GPU "
+                          "process (one busy host thread); joined before the timed region (waited %.1f s there)" % self.waited_s)
+            return rec
+        self.err.seek(0)
+        print("bench: cpu-baseline child failed (rc %s): %s - running it in this process" %
+              (self.proc.returncode, self.err.read()[-400:]), file=sys.stderr, flush=True)
+        return cpu_baseline(*self.args)
+
+
+def converged_ok(lam, resid, resid_re, tol, spec):
+    """The parity guard of a bench line: finite eigenvalues, the reference tests' residual bar (1e-8,
+    tests/chase_serial_solve.cpp:144-148) on the solver's and on the independently recomputed residuals, the analytic
+    spectrum, and the solver's OWN tolerance on what the reference would see: no pair the solver took as converged
+    (residual <= tol; stagnating pairs are locked above it on purpose, algorithm.inc:519-578) may be above tol when its
+    residual is recomputed from a fresh four-product H v (two correct evaluations of one residual differ by ~1e-14 ||H||,
+    i.e. ~1e-4 tol: the bar is tol (1 + 1e-3))."""
+    lam, resid, resid_re = np.asarray(lam), np.asarray(resid), np.asarray(resid_re)
+    above = int(np.sum((resid <= tol) & (resid_re > tol * (1 + 1e-3))))
+    return bool(np.all(np.isfinite(lam)) and np.max(resid) < 1e-8 and np.max(resid_re) < 1e-8 and above == 0
+                and (spec is None or spec["ok"]))
+
+
 class StepTimer:
     """Times exactly `steps` outer iterations after `warmup` untimed ones, across back-to-back solves.
 
     sync(): device synchronisation of this rank; barrier(): all ranks; snapshot(): dict of cumulative counters.  The
     boundaries are bracketed sync -> barrier -> clock on both sides, like the contract asks for whole steps."""
 
-    def __init__(self, steps, warmup, sync, barrier, snapshot):
+    def __init__(self, steps, warmup, sync, barrier, snapshot, progress=None, before_timed=None):
         self.steps, self.warmup = steps, warmup
         self.sync, self.barrier, self.snapshot = sync, barrier, snapshot
+        self.before_timed = before_timed      # called once, right before the opening bracket of the timed region
         self.boundary = 0                     # outer iterations completed so far (all solves)
         self.t0 = self.t1 = None
         self.c0 = self.c1 = None
@@ -191,7 +251,9 @@ class StepTimer:
         self.solve_index = 0
         self.complete_solves = 0
         self._last = None
-        self.progress = os.environ.get("RANK", "0") == "0" and os.environ.get("CHASE_BENCH_QUIET") != "1"
+        if progress is None:
+            progress = os.environ.get("RANK", "0") == "0"
+        self.progress = progress and os.environ.get("CHASE_BENCH_QUIET") != "1"
 
     @property
     def running(self):
@@ -208,6 +270,8 @@ class StepTimer:
 
     def start_if_due(self):
         if self.t0 is None and self.boundary == self.warmup:
+            if self.before_timed is not None:
+                self.before_timed()
             self.t0, self.c0 = self._bracket()
             self._last = self.t0
 
@@ -263,8 +327,7 @@ def fullwidth_probe(s, ctx, N, cplx, nevex, three_m, reps=4):
         s.Start()
         s.initVecs(True)
         check(lib.chase_hip_ctx_set_phase(ctx.h, 1), "set_phase")
-        s.HEMM(nevex, 0.01, 0.0, 0)                      # untimed: first launch of this instantiation
-        s.HEMM(nevex, 0.01, -0.5, 0)
+        s.HEMM(nevex, 0.01, -0.5, 0)                     # untimed: first launch of this instantiation
         ctx.sync()
         m0, e0, n0 = gemm_counters(ctx, 1)
         ctx.timer_start()
@@ -304,9 +367,6 @@ def roofline_object(model_flops, exec_flops, filt_s, calls, world, note_extra=""
             "executed_over_model": exec_flops / model_flops if model_flops else None,
             "launches": calls, "avg_launch_ms": filt_s * 1e3 / max(calls, 1),
             "flop_per_launch_avg": model_flops / max(calls, 1) / world,
-            # what a register-resident loop of v_mfma_f64_16x16x4_f64 sustains on this part (64.00 cycles per instruction at
-            # 2.39 GHz, scripts/dev_mfma_f64_peak.hip, profiles/r02_mfma_f64_issue.txt): context for `frac`, not its denominator
-            "bare_mfma_loop_tflops": 77.5,
             "launch_unit": "one HEMM call per GPU = whole-tile kernel (+ ragged-column kernel when the width is not a "
                            "multiple of the tile width) + tail reduce; rocprofv3: sum over the TAG=1 kernels",
             "note": "achieved/frac = flops the matrix cores EXECUTE (the complex filter kernel forms each complex product "
@@ -322,6 +382,9 @@ def attach_traffic(out, workload):
             rec = json.load(open(pmc))
             if rec.get("workload") == workload:
                 out["roofline"]["traffic"] = rec.get("hbm_bytes_per_launch")
+                out["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json (%s): a separate rocprofv3 --pmc pass over "
+                                                     "one full-width launch of this kernel, NOT measured in this run"
+                                                     % rec.get("source", "see the file"))
                 out["roofline"]["traffic_note"] = rec.get("note")
         except Exception:
             pass
@@ -333,6 +396,7 @@ def run_single(args):
     if args.n:
         N = args.n
     nevex = nev + nex
+    cpu_job = None if args.no_cpu_baseline else CpuBaselineJob(N, cplx, nevex, args.cpu_budget)
     ctx = Context(0)
     info = ctx.info()
     dH = ctx.gen_clement(N, cplx, scale=MATRIX_SCALE / N, perturb=MATRIX_PERTURB, seed=42)
@@ -346,7 +410,8 @@ def run_single(args):
         return {"filter_ms": s.get("filter_ms"), "hemm_calls": s.get("hemm_calls"),
                 "reused": s.get("hemm_reused_vecs"), "model": model, "exec": execd, "gemms": calls}
 
-    timer = StepTimer(args.steps, args.warmup, ctx.sync, lambda: None, snapshot)
+    timer = StepTimer(args.steps, args.warmup, ctx.sync, lambda: None, snapshot,
+                      before_timed=(cpu_job.join if cpu_job is not None else None))
     complete, last = run_timed_solves(s, timer, nev, lambda: (s.ritzv[:nev].copy(), s.resid()[:nev].copy()))
     wall = timer.t1 - timer.t0
     filt_s = timer.diff("filter_ms") * 1e-3
@@ -364,7 +429,7 @@ def run_single(args):
     # one fresh four-product H V over the nev eigenvectors of the last solve + the residual-norm kernel.  The solver's own
     # residuals come from (H Q) A left behind by Rayleigh-Ritz, these from H itself.
     resid_re = s.recompute_residuals(nev, lam)
-    ok = bool(np.all(np.isfinite(lam)) and np.max(resid) < 1e-8 and np.max(resid_re) < 1e-8 and spec["ok"])
+    ok = converged_ok(lam, resid, resid_re, s.get("tol"), spec)
     st = complete[-1]
     solve_s = float(np.mean([c["t_all"] for c in complete]))
     out = {
@@ -379,6 +444,7 @@ def run_single(args):
         "eigenpairs_per_sec": nev / solve_s, "solve_seconds": solve_s, "complete_solves": len(complete),
         "pct_fp64_mfma_peak": 100.0 * exec_flops / filt_s / 1e12 / FP64_MFMA_PEAK_TFLOPS,
         "converged": ok, "max_resid": float(np.max(resid)), "max_resid_recomputed": float(np.max(resid_re)),
+        "residuals_rechecked_on_the_tolerance": int(s.get("resd_rechecked")),
         "spectrum_check": spec,
         "iterations_per_solve": st["iterations"], "filtered_vecs_per_solve": st["filtered_vecs"],
         "timed": {"filtered_vecs": timer.filtered_timed, "hemm_vecs": hemm_vecs, "first_step_vecs_from_rr": reused,
@@ -403,8 +469,8 @@ def run_single(args):
     s.close()
     del dH
     ctx.close()
-    if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(N, cplx, nevex, args.cpu_budget)
+    if cpu_job is not None:
+        out["cpu_baseline"] = cpu_job.result()
     return out
 
 
@@ -456,30 +522,48 @@ def bind_one_device(env, local_rank):
     return pick
 
 
-def spawn_ranks(args, argv):
-    """`python bench.py --gpus N` (N > 1) without a launcher: start N ranks of this script as child processes — one per
-    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set like torch.distributed.run does (the reference bootstraps its own
-    communicators too, grid/mpiGrid2D.hpp:448-484).  Nothing in this parent has touched HIP or torch.  Rank 0's JSON line
-    is relayed as the last line of stdout; the exit status is non-zero if any rank failed."""
+# ---- how the ranks of a multi-GPU run hold their devices -------------------------------------------------------------------
+# "bound":   one process per GPU, each process's ROCm runtime sees ONLY its device (ROCR_VISIBLE_DEVICES): one process per
+#            card (the pool's boxes allow few), RCCL must reach the invisible peers through IPC handles
+# "unbound": one process per GPU, all devices visible, device = local rank - what the reference does
+#            (grid/mpiGrid2D.hpp:225-233) and what RCCL is tested with most; every process opens every card
+# "threads": ONE process, one thread per GPU - no IPC, no visibility question, one process per card; under
+#            torch.distributed.run rank 0 hosts the threads and the other ranks leave without touching the GPU
+# `--ranks auto` tries them in this order with short-lived PROBE children (bench.py --transport-probe: context, RCCL
+# communicators, the 256 MB all-reduce proof) started before this process has touched the GPU; the first mode whose probe
+# exits 0 runs the bench.  A mode is never switched inside a process that has initialised HIP.
+MODES = ("bound", "unbound", "threads")
+PROBE_TIMEOUT_S = float(os.environ.get("CHASE_BENCH_PROBE_TIMEOUT", "240"))
+
+
+def mode_env(env, mode, local_rank):
+    """environment of a rank process in `mode` (edits a copy)"""
+    env = dict(env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("CHASE_HIP_BOUND_DEVICE", None)
+    if mode == "bound":
+        env["CHASE_HIP_BIND"] = "1"
+        bind_one_device(env, local_rank)
+    else:
+        env["CHASE_HIP_BIND"] = "0"
+    return env
+
+
+def free_port():
     import socket
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    n = args.gpus
-    procs, outs = [], []
-    for r in range(n):
-        env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        bind_one_device(env, r)
-        f = tempfile.TemporaryFile(mode="w+") if r == 0 else None
-        outs.append(f)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=f if f is not None else sys.stderr, stderr=sys.stderr))
-    rc = 0
+        return so.getsockname()[1]
+
+
+def run_children(cmds_envs, timeout_s):
+    """Starts the given (argv, env, stdout) children, waits for all of them; the first failure stops the others (exactly the
+    processes started here).  Returns the first non-zero exit status (124 for a timeout), else 0."""
+    procs = [subprocess.Popen(argv, env=env, stdout=out if out is not None else sys.stderr, stderr=sys.stderr)
+             for argv, env, out in cmds_envs]
+    rc, t0 = 0, time.perf_counter()
     try:
-        alive = set(range(n))
+        alive = set(range(len(procs)))
         while alive:
             for r in sorted(alive):
                 code = procs[r].poll()
@@ -490,14 +574,89 @@ def spawn_ranks(args, argv):
                     rc = code if code > 0 else 1
                     print(f"bench: rank {r} exited with status {code}; stopping the other ranks", file=sys.stderr)
                     for q in alive:
-                        procs[q].terminate()           # exactly the processes started above
+                        procs[q].terminate()
+            if alive and timeout_s and time.perf_counter() - t0 > timeout_s:
+                print(f"bench: ranks still running after {timeout_s:.0f} s; stopping them", file=sys.stderr)
+                rc = rc or 124
+                for q in alive:
+                    procs[q].terminate()
+                timeout_s = None
             time.sleep(0.2)
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    outs[0].seek(0)
-    lines = [l.rstrip("\n") for l in outs[0].read().splitlines() if l.strip()]
+    return rc
+
+
+def fake_probe_rc(mode):
+    """test hook (tests/test_bench_contract.py): CHASE_BENCH_FAKE_PROBE='{"bound": 5, "unbound": 0}' answers the probe of a
+    mode without touching a GPU"""
+    spec = os.environ.get("CHASE_BENCH_FAKE_PROBE")
+    if not spec:
+        return None
+    return int(json.loads(spec).get(mode, 1))
+
+
+def choose_mode_as_parent(args, argv):
+    """`python bench.py --gpus N` without a launcher: try the process modes with N probe children each"""
+    n = args.gpus
+    for mode in MODES[:2]:
+        rc = fake_probe_rc(mode)
+        if rc is None:
+            port = free_port()
+            kids = []
+            for r in range(n):
+                env = mode_env(os.environ, mode, r)
+                env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                           MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                kids.append(([sys.executable, os.path.abspath(__file__)] + argv + ["--transport-probe"], env, None))
+            rc = run_children(kids, PROBE_TIMEOUT_S)
+        print(f"bench: probe of mode '{mode}': exit status {rc}", file=sys.stderr, flush=True)
+        if rc == 0:
+            return mode
+    return "threads"
+
+
+def choose_mode_as_rank(args, argv):
+    """Under torch.distributed.run: this process is one of N rank processes and has NOT touched the GPU.  Every rank starts
+    its own probe child per candidate mode; the children of all ranks meet on a port derived from MASTER_PORT, agree on the
+    outcome among themselves and exit with the same status, so every rank reaches the same decision without talking."""
+    rank = int(os.environ["RANK"])
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    base = int(os.environ.get("MASTER_PORT", "29500"))
+    for i, mode in enumerate(MODES[:2]):
+        rc = fake_probe_rc(mode)
+        if rc is None:
+            env = mode_env(os.environ, mode, local_rank)
+            env["MASTER_PORT"] = str(base + 101 + i if base + 101 + i < 65536 else base - 101 - i)
+            env["CHASE_BENCH_QUIET"] = "1"
+            rc = run_children([([sys.executable, os.path.abspath(__file__)] + argv + ["--transport-probe"], env, None)],
+                              PROBE_TIMEOUT_S)
+        if rank == 0:
+            print(f"bench: probe of mode '{mode}': exit status {rc}", file=sys.stderr, flush=True)
+        if rc == 0:
+            return mode
+    return "threads"
+
+
+def spawn_ranks(args, argv, mode):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start N ranks of this script as child processes — one per
+    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set like torch.distributed.run does (the reference bootstraps its own
+    communicators too, grid/mpiGrid2D.hpp:448-484).  Nothing in this parent has touched HIP or torch.  Rank 0's JSON line
+    is relayed as the last line of stdout; the exit status is non-zero if any rank failed."""
+    port = free_port()
+    n = args.gpus
+    out0 = tempfile.TemporaryFile(mode="w+")
+    kids = []
+    for r in range(n):
+        env = mode_env(os.environ, mode, r)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CHASE_BENCH_MODE=mode)
+        kids.append(([sys.executable, os.path.abspath(__file__)] + argv, env, out0 if r == 0 else None))
+    rc = run_children(kids, None)
+    out0.seek(0)
+    lines = [l.rstrip("\n") for l in out0.read().splitlines() if l.strip()]
     js = [l for l in lines if l.startswith("{") and l.endswith("}")]
     for l in lines:
         if not js or l is not js[-1]:
@@ -525,20 +684,45 @@ def main():
                     help="run the grid Impl (pChaseHip) even on one GPU (1x1 grid; development: panel-pipeline overheads)")
     ap.add_argument("--block-cyclic", type=int, default=-1,
                     help="block size of a block-cyclic H distribution (0 = block layout, -1 = the workload's default)")
+    ap.add_argument("--ranks", default="auto", choices=("auto", "processes", "threads") + MODES,
+                    help="how the ranks of a multi-GPU run hold their devices: processes (= bound: one process per GPU, one "
+                         "visible device each), unbound (all devices visible), threads (one process, one thread per GPU), "
+                         "auto (default): the first of bound / unbound / threads whose transport probe passes")
+    ap.add_argument("--transport-probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        # CPU-only child of CpuBaselineJob: numpy / scipy / the oracle, nothing that touches a GPU
+        N, cplx, ncols, budget = args.cpu_baseline_child.split(",")
+        print(json.dumps(cpu_baseline(int(N), bool(int(cplx)), int(ncols), float(budget))), flush=True)
+        return
     if args.steps < 1 or args.warmup < 0:
         ap.error("need --steps >= 1 and --warmup >= 0")
     if args.workload is None:
         args.workload = DEFAULT_WORKLOAD
+    if args.ranks == "processes":
+        args.ranks = "bound"
+    argv = [a for a in sys.argv[1:] if a != "--transport-probe"]
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
-    if args.gpus > 1 and not launched:
-        # BEFORE anything initialises HIP / torch in this process
-        sys.exit(spawn_ranks(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
-    if launched and world > 1 and "CHASE_HIP_BOUND_DEVICE" not in os.environ:
-        # started by torch.distributed.run (the driver's multi-GPU call): nothing in this process has touched HIP yet
-        # (numpy only), so the binding can still be made here, in place
-        bind_one_device(os.environ, int(os.environ.get("LOCAL_RANK", os.environ["RANK"])))
+    host_transport = os.environ.get("CHASE_HIP_TRANSPORT") == "host"
+
+    # ---- settle the mode of a multi-GPU run BEFORE anything initialises HIP / torch in this process ---------------------
+    mode = os.environ.get("CHASE_BENCH_MODE") or (args.ranks if args.ranks != "auto" else None)
+    if mode is None and os.environ.get("CHASE_HIP_BIND") == "0":
+        mode = "unbound"                                 # (round 3's switch, kept)
+    if args.gpus > 1 and not launched:
+        if mode is None:
+            mode = "bound" if host_transport else choose_mode_as_parent(args, argv)
+        if mode != "threads":
+            sys.exit(spawn_ranks(args, argv, mode))
+    elif launched and world > 1 and not args.transport_probe:
+        if mode is None:
+            mode = "bound" if host_transport else choose_mode_as_rank(args, argv)
+        if mode == "threads" and int(os.environ["RANK"]) != 0:
+            return                                       # rank 0 hosts the threads; this rank never touches the GPU
+        if mode in ("bound", "unbound"):
+            os.environ.update(mode_env(os.environ, mode, int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # stdout carries the ONE JSON line and nothing else: whatever libraries write to file descriptor 1 on the way (gloo's
     # connection notes, RCCL's banner) is sent to stderr, the line goes to the real stdout at the end
@@ -550,16 +734,16 @@ def main():
         if out is not None:
             os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
+    if mode == "threads" and (args.gpus > 1 or world > 1):
+        from chase_amd.dist_bench import run_threads
+        emit(run_threads(args, max(args.gpus, world)))
+        return
     if world > 1 or args.dist or args.workload in PSEUDO_WORKLOADS:
         if not launched:
             # grid Impl on a 1x1 grid (communicator-free) when started directly on one GPU
-            import socket
-            with socket.socket() as so:
-                so.bind(("127.0.0.1", 0))
-                port = so.getsockname()[1]
-            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
         from chase_amd.dist_bench import run_distributed
-        emit(run_distributed(args))
+        emit(run_distributed(args, probe_only=args.transport_probe))
         return
     emit(run_single(args))
 

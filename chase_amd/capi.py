@@ -124,6 +124,7 @@ class Context:
         h = c_void_p()
         check(lib.chase_hip_ctx_create(C.byref(h), device, stream), "chase_hip_ctx_create")
         self.h = h
+        self.device = device
         self._live = []
 
     def close(self):
@@ -248,6 +249,7 @@ _sig("chase_hip_conj", c_int, c_void_p, c_int, c_int, c_void_p, c_long)
 _sig("chase_hip_resid_norms", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p,
      c_void_p, c_int)
 _sig("chase_hip_herk", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long)
+_sig("chase_hip_herkx", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int)
 _sig("chase_hip_abs_trace", c_int, c_void_p, c_int, c_int, c_void_p, c_long, P(c_double))
 _sig("chase_hip_potrf_upper", c_int, c_void_p, c_int, c_int, c_void_p, c_long)
 _sig("chase_hip_trsm_right_upper", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long)

@@ -279,14 +279,41 @@ int chase_hip_conj(chase_hip_ctx* c, int m, int n, void* X, long ldx)
     return 0;
 }
 
-/* A(n x n) = V^H V, V is k x n.  Full matrix is produced (upper triangle is what CholQR consumes). */
+/* C (n x n) = A^H B for k x n operands whose product is Hermitian (A = B: the Gram matrix of CholQR; A = H Q, B = Q: the
+ * projected matrix of Rayleigh-Ritz) - what cublasTsyherk / herkx compute (cuda/cholqr.hpp:110-112).  Only the tiles that
+ * touch the upper triangle are multiplied: the result is built block column by block column, column block J from the
+ * rows 0 .. end(J) of op(A) only, i.e. (1 + 1/nblocks) / 2 of the flops of the full product (55 % at n = 2560 with blocks
+ * of 256 columns; every piece is K-split over the chip like any short-and-fat product).  mirror != 0 rebuilds the strictly
+ * lower triangle from the upper one; otherwise it is left untouched.  Small products (n < 4 blocks) take the one GEMM. */
+int chase_hip_herkx(chase_hip_ctx* c, int cplx, int n, int k, const void* A_, long lda, const void* B_, long ldb, void* C_,
+                    long ldc, int mirror)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "herkx: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    const long kmin = k > 1 ? k : 1;
+    if (n < 0 || k < 0 || lda < kmin || ldb < kmin || ldc < n) return set_error(CHASE_HIP_EINVAL, "herkx: bad shape");
+    if (n == 0) return 0;
+    const int e = ept_of(cplx);
+    const double *A = (const double*)A_, *B = (const double*)B_;
+    double* C = (double*)C_;
+    static const int wb_env = [] { const char* s = getenv("CHASE_HIP_HERK_BLOCK"); return s ? atoi(s) : 256; }();
+    const int wb = wb_env > 0 ? (wb_env + 127) / 128 * 128 : 0;       // whole row tiles of the product (0: one GEMM)
+    if (wb == 0 || n < 4 * wb) {
+        RCCHK(gemm(c, cplx, 'C', n, n, k, 1.0, 0.0, A, lda, B, ldb, 0.0, 0.0, C, ldc));
+    } else {
+        for (int j0 = 0; j0 < n; j0 += wb) {
+            const int w = (n - j0 < wb) ? n - j0 : wb, rows = j0 + w;
+            RCCHK(gemm(c, cplx, 'C', rows, w, k, 1.0, 0.0, A, lda, B + (long)j0 * ldb * e, ldb, 0.0, 0.0, C + (long)j0 * ldc * e, ldc));
+        }
+    }
+    if (mirror) KCHK(mirror_upper(c->stream, C, ldc, n, e), "mirror_upper");
+    return 0;
+}
+
+/* A(n x n) = V^H V, V is k x n: upper triangle computed (what CholQR consumes), lower triangle mirrored from it */
 int chase_hip_herk(chase_hip_ctx* c, int cplx, int n, int k, const void* V, long ldv, void* A, long lda)
 {
-    if (!c) return set_error(CHASE_HIP_EINVAL, "herk: NULL ctx");
-    (void)hipSetDevice(c->device);      // entry points may be called with another device current
-    if (n < 0 || k < 0 || ldv < (k > 1 ? k : 1) || lda < n) return set_error(CHASE_HIP_EINVAL, "herk: bad shape");
-    return gemm(c, cplx, 'C', n, n, k, 1.0, 0.0, (const double*)V, ldv, (const double*)V, ldv, 0.0, 0.0, (double*)A,
-                lda);
+    return chase_hip_herkx(c, cplx, n, k, V, ldv, V, ldv, A, lda, 1);
 }
 
 int chase_hip_abs_trace(chase_hip_ctx* c, int cplx, int n, const void* A, long lda, double* out_host)
@@ -453,6 +480,35 @@ int chase_hip_heevd(chase_hip_ctx* c, int cplx, int n, void* A, long lda, double
     return 0;
 }
 
+/* The dense core of the pseudo-Hermitian Rayleigh-Ritz on the device (cpu/rayleighRitz.hpp:316-383 restated with the
+ * entry points of this library; the reference's GPU path: cuda/rayleighRitz.hpp:511-600).  With A = R^H R (upper Cholesky)
+ * and X = R^{-1} (one right-solve on the identity): B = -X^H M X through two MFMA GEMMs, (w, Z) = heevd(B), Ritz vectors
+ * X Z, Ritz values 1 / (-w), first n/2 vectors normalised - the same steps in the same order as host_pseudo_rr (lower
+ * Cholesky L = R^H, three triangular solves).  A and M are consumed; the vectors come back in M. */
+static int pseudo_rr_device(chase_hip_ctx* c, int cplx, int n, double* A, double* M, double* w_host)
+{
+    const int e = ept_of(cplx);
+    const size_t bytes = (size_t)n * n * sizeof(double) * e;
+    int info = chase_hip_potrf_upper(c, cplx, n, A, n);
+    if (info != 0) return info;                                   // > 0: A = Q^H S H Q is not positive definite
+    RCCHK(c->ensure_buf(chase_hip_ctx::BUF_RR, bytes));
+    double* X = (double*)c->bufs[chase_hip_ctx::BUF_RR];
+    RCCHK(chase_hip_set_identity(c, cplx, n, X, n));
+    RCCHK(chase_hip_trsm_right_upper(c, cplx, n, n, A, n, X, n));                                   // X = R^{-1}
+    RCCHK(gemm(c, cplx, 'N', n, n, n, 1.0, 0.0, M, n, X, n, 0.0, 0.0, A, n));                       // A <- M X   (R is spent)
+    RCCHK(gemm(c, cplx, 'C', n, n, n, -1.0, 0.0, X, n, A, n, 0.0, 0.0, M, n));                      // M <- -X^H M X
+    RCCHK(chase_hip_heevd(c, cplx, n, M, n, w_host));                                               // ascending w, Z in M
+    RCCHK(gemm(c, cplx, 'N', n, n, n, 1.0, 0.0, X, n, M, n, 0.0, 0.0, A, n));                       // A <- X Z = L^{-H} Z
+    for (int i = 0; i < n; ++i) w_host[i] = 1.0 / (-w_host[i]);
+    RCCHK(c->ensure_buf(chase_hip_ctx::BUF_SCAL, 4096 + (size_t)n * sizeof(double)));
+    double* nrm = (double*)((char*)c->bufs[chase_hip_ctx::BUF_SCAL] + 4096);
+    RCCHK(chase_hip_col_nrm2(c, cplx, n, n / 2, A, n, nrm));
+    RCCHK(chase_hip_col_scal(c, cplx, n, n / 2, nrm, 1, A, n));
+    HIPCHK(hipMemcpyAsync(M, A, bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 /* Pseudo-Hermitian Rayleigh-Ritz, small dense part on the host (cpu/rayleighRitz.hpp:316-383): device A = Q^H S H Q and
  * M = Q^H S Q (both n x n, ld n) -> device M = back-transformed Ritz vectors (first n/2 columns normalised), Ritz values
  * to ritzv_host.  Returns the potrf info (> 0) if A is not positive definite. */
@@ -468,9 +524,12 @@ int chase_hip_pseudo_rr_small(chase_hip_ctx* c, int cplx, int n, void* A_dev, vo
     HIPCHK(hipMemcpyAsync(hA, A_dev, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(hM, M_dev, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    // large cores (config 5: 2 (nev + nex) = 640): the Hermitian eigenproblem in the middle goes through chase_hip_heevd, i.e.
-    // tridiagonalisation / divide & conquer / back-transformation on the device; potrf and the three trsm stay on the host
+    // large cores (config 5: 2 (nev + nex) = 640): everything on the device like the reference's GPU path
+    // (linalg/internal/cuda/rayleighRitz.hpp:511-600: cusolver potrf, cublas trsm, cusolver heevd) - see pseudo_rr_device;
+    // CHASE_HIP_PSEUDO_RR_DEVICE=0 keeps round 3's split (potrf and the three trsm on the host, heevd on the device)
     static const int gpu_min = [] { const char* e = getenv("CHASE_HIP_HEEVD_GPU_MIN"); return e ? atoi(e) : 384; }();
+    static const bool dev_core = [] { const char* e = getenv("CHASE_HIP_PSEUDO_RR_DEVICE"); return e ? atoi(e) != 0 : true; }();
+    if (gpu_min > 0 && n >= gpu_min && dev_core) return pseudo_rr_device(c, cplx, n, (double*)A_dev, (double*)M_dev, ritzv_host);
     if (gpu_min > 0 && n >= gpu_min) {
         int rc = host_pseudo_rr_pre(cplx != 0, n, hA, hM);
         if (rc) return rc;

@@ -237,7 +237,7 @@ int chase_hip_set_gemm3m(int on)
 int chase_hip_ctx_gemm_counters(chase_hip_ctx* c, int phase, double* flops_model, double* flops_executed,
                                 unsigned long long* calls, int reset)
 {
-    if (!c || phase < 0 || phase > 2) return set_error(CHASE_HIP_EINVAL, "gemm_counters: bad argument");
+    if (!c || phase < 0 || phase > 3) return set_error(CHASE_HIP_EINVAL, "gemm_counters: bad argument");
     if (flops_model) *flops_model = c->flops_model[phase];
     if (flops_executed) *flops_executed = c->flops_exec[phase];
     if (calls) *calls = c->gemm_calls[phase];

@@ -13,16 +13,17 @@ struct chase_hip_ctx {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int phase = 0;               // 1 between FilterPhaseStart/End: selects the filter-tagged GEMM symbol
-    // GEMM accounting per phase (0 other, 1 filter, 2 H-times-block outside the filter): flops of the reference's model
-    // (2*F*m*n*k, F = 4 complex) and flops the matrix cores executed (3/4 of it for three-multiplication launches)
-    double flops_model[3] = {0, 0, 0}, flops_exec[3] = {0, 0, 0};
-    unsigned long long gemm_calls[3] = {0, 0, 0};
+    // GEMM accounting per phase (0 other, 1 filter, 2 H-times-block outside the filter, 3 verification products: always
+    // four multiplications): flops of the reference's model (2*F*m*n*k, F = 4 complex) and flops the matrix cores executed
+    // (3/4 of it for three-multiplication launches)
+    double flops_model[4] = {0, 0, 0, 0}, flops_exec[4] = {0, 0, 0, 0};
+    unsigned long long gemm_calls[4] = {0, 0, 0, 0};
     int gemm_min_rounds = 0;          // > 0: products share the chip with a collective (chase_hip_ctx_set_gemm_min_rounds)
     void* ws = nullptr;          // split-K slabs, grown on demand
     size_t ws_bytes = 0;
-    enum { BUF_TINV = 0, BUF_PANEL, BUF_SCAL, BUF_LAMBDA, NBUF };
-    void* bufs[NBUF] = {nullptr, nullptr, nullptr, nullptr};   // device scratch, grown on demand
-    size_t buf_bytes[NBUF] = {0, 0, 0, 0};
+    enum { BUF_TINV = 0, BUF_PANEL, BUF_SCAL, BUF_LAMBDA, BUF_RR, BUF_EIG, BUF_STEDC, NBUF };
+    void* bufs[NBUF] = {};   // device scratch, grown on demand (BUF_EIG / BUF_STEDC: the projected eigensolver's blocks)
+    size_t buf_bytes[NBUF] = {};
     void* hstage = nullptr;      // pinned host staging (HEEVD round trip)
     size_t hstage_bytes = 0;
 

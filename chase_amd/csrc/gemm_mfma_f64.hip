@@ -980,9 +980,9 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
         (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, true, false, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set[dev].store(true, std::memory_order_relaxed);
     }
-    // complex HEMMs of the filter phase (tag 1) run the 3-product scheme unless CHASE_HIP_GEMM3M=0 / gemm3m_set(0);
-    // everything else - Rayleigh-Ritz and residual products (the convergence test), Gram products, back-transforms -
-    // stays on four products like the reference's zgemm (CHASE_HIP_GEMM3M_RR=1 opts the tag-2 H-times-block products in)
+    // complex HEMMs of the filter phase (tag 1) and the H-times-block products of Rayleigh-Ritz / residuals (tag 2, see
+    // gemm_f64) run the 3-product scheme unless CHASE_HIP_GEMM3M=0 / gemm3m_set(0); everything else - Gram products,
+    // back-transforms, QR, verification products (tag 3) - stays on four products like the reference's zgemm
     constexpr bool CAN3M = CPLX;
     const bool want3m = gemm3m_enabled() != 0;
     // the 3M instantiation has no register-staged fallback: whole row tiles, whole K tiles, 16-byte addressable operands
@@ -1154,7 +1154,11 @@ int gemm_f64(hipStream_t st, bool cplx, char opA, int m, int n, int k, const dou
 {
     const bool opc = (opA == 'C' || opA == 'c' || opA == 'T' || opA == 't');
     const LaunchInfo li{device, exec_flops, min_rounds};
-    static const bool rr3m = [] { const char* e = getenv("CHASE_HIP_GEMM3M_RR"); return e && atoi(e) != 0; }();
+    // tag 2 = the H-times-block products of Rayleigh-Ritz and of the residual step: three multiplications like the filter
+    // since round 4 (the residuals that decide locking are re-taken from a fresh four-product H v whenever they come within
+    // 1e-3 of the tolerance, chase_hip_impl.hpp Resd; CHASE_HIP_GEMM3M_RR=0 restores four products); tag 3 = verification
+    // products (recompute_residuals, the borderline re-check): four multiplications, always
+    static const bool rr3m = [] { const char* e = getenv("CHASE_HIP_GEMM3M_RR"); return e ? atoi(e) != 0 : true; }();
     const bool allow2 = (tag == 2) && rr3m;
 #define CHASE_GEMM_DISPATCH(CP, OC)                                                                                    \
     (tag == 1 ? launch_gemm<CP, OC, 1>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ws, ws_bytes, num_cu, true, li) \

@@ -443,7 +443,7 @@ using namespace chase_hip;
 #define HC(x)                                                                                                          \
     do {                                                                                                               \
         hipError_t e_ = (x);                                                                                           \
-        if (e_ != hipSuccess) return hip_fail(e_, #x);                                                                 \
+        if (e_ != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e_, #x); }                             \
     } while (0)
 
 /* Hermitian eigendecomposition of the device matrix A (n x n, full storage, lower triangle authoritative):
@@ -464,9 +464,10 @@ extern "C" int chase_hip_heevd_gpu(chase_hip_ctx* c, int cplx_, int n, void* A_,
     const size_t szv = (size_t)n * E, szpart = (size_t)nch_max * n * E, szZ = (size_t)n * n;
     // blocked reduction: panel buffer X = [V | W] (n x 2 LNB), YH (2 LNB x n), coefficients, scalars, partial norms
     const size_t szX = (size_t)2 * LNB * n * E, szY = szX, szSmall = (size_t)4 * LNB + 16 + (size_t)nrb_max + 8;
-    double* blk = nullptr;
-    hipError_t he = hipMalloc((void**)&blk, (2 * szv + szpart + 2 * nrb_max + 2 * (size_t)n + szv + szZ + szZ * E + 64 + szX + szY + szSmall) * sizeof(double));
-    if (he != hipSuccess) return set_error(CHASE_HIP_ENOMEM, "heevd_gpu: scratch allocation failed");
+    // context-owned, grow-only block (round 3: hipMalloc + hipFree - a device-wide synchronisation - in every call)
+    rc = c->ensure_buf(chase_hip_ctx::BUF_EIG, (2 * szv + szpart + 2 * nrb_max + 2 * (size_t)n + szv + szZ + szZ * E + 64 + szX + szY + szSmall) * sizeof(double));
+    if (rc) return rc;
+    double* blk = (double*)c->bufs[chase_hip_ctx::BUF_EIG];
     double* vbuf = blk; double* pbuf = vbuf + szv; double* part = pbuf + szv; double* dots = part + szpart;
     double* dd = dots + 2 * nrb_max; double* de = dd + n; double* tau = de + n; double* Zr = tau + szv; double* Zc = Zr + szZ;
     double* Xp = Zc + szZ * E + 64; double* YH = Xp + szX; double* coef = YH + szY; double* scal = coef + 4 * LNB;
@@ -592,6 +593,5 @@ extern "C" int chase_hip_heevd_gpu(chase_hip_ctx* c, int cplx_, int n, void* A_,
     };
     rc = body();
     hipStreamSynchronize(st);
-    hipFree(blk);
     return rc;
 }

@@ -115,8 +115,12 @@ __global__ __launch_bounds__(256) void dc_secular_kernel(int k, const double* __
         if ((g >= 0.0) == (sgn > 0.0)) hi_b = mid; else lo_b = mid;
     }
     const double vlo = __longlong_as_double(lo_b), vhi = __longlong_as_double(hi_b);
-    const double v = fabs(G(o, sgn * vlo)) < fabs(G(o, sgn * vhi)) ? vlo : vhi;
-    if (lane == 0) { org[j] = o; mu[j] = sgn * v; lam[j] = dl[o] + sgn * v; }
+    const double glo = G(o, sgn * vlo), ghi = G(o, sgn * vhi);
+    const double v = fabs(glo) < fabs(ghi) ? vlo : vhi;
+    // a NaN secular function (garbage operands, a degenerate merge) would have steered the bisection silently - !(NaN >= 0)
+    // reads as "negative": report it through the root, which the host checks for finiteness before it goes on
+    const bool bad = (glo != glo) || (ghi != ghi);
+    if (lane == 0) { org[j] = o; mu[j] = sgn * v; lam[j] = bad ? __longlong_as_double(0x7ff8000000000000ll) : dl[o] + sgn * v; }
 }
 
 // Gu-Eisenstat: z^_i = sign(z_i) sqrt( prod_j (lambda_j - dl_i) / prod_{j != i} (dl_j - dl_i) ), one wave per i
@@ -138,7 +142,8 @@ __global__ __launch_bounds__(256) void dc_zhat_kernel(int k, const double* __res
 
 // column j of the eigenvector matrix of D + rho z^ z^^T: S_ij = z^_i / (dl_i - lambda_j), normalised; one workgroup per column
 __global__ __launch_bounds__(256) void dc_vectors_kernel(int k, const double* __restrict__ dl, const double* __restrict__ zhat,
-                                                         const int* __restrict__ org, const double* __restrict__ mu, double* __restrict__ S, long lds)
+                                                         const int* __restrict__ org, const double* __restrict__ mu, double* __restrict__ S, long lds,
+                                                         double* __restrict__ lam)
 {
     __shared__ double part[4];
     const int j = blockIdx.x;
@@ -155,6 +160,9 @@ __global__ __launch_bounds__(256) void dc_vectors_kernel(int k, const double* __
     __syncthreads();
     const double inv = 1.0 / sqrt((part[0] + part[1]) + (part[2] + part[3]));
     for (int i = threadIdx.x; i < k; i += 256) col[i] *= inv;
+    // a vector that cannot be normalised (non-finite or zero norm: garbage z^, a degenerate merge) must not reach the Ritz
+    // vectors: poison its eigenvalue, which the host checks after this level (-> host solver)
+    if (threadIdx.x == 0 && !(inv > 0.0 && inv <= 1.79769313486231570815e308)) lam[j] = __longlong_as_double(0x7ff8000000000000ll);
 }
 
 struct Merge {
@@ -165,16 +173,18 @@ struct Merge {
     int rot0 = 0, nrot = 0; // slice of the level's rotation list
 };
 
+// error exits wait for the stream first: pageable host vectors that an asynchronous copy may still read go out of scope
+// with the return (`st` is the stream variable of the enclosing function)
 #define DCHK(x)                                                                                                        \
     do {                                                                                                               \
         hipError_t e_ = (x);                                                                                           \
-        if (e_ != hipSuccess) return hip_fail(e_, #x);                                                                 \
+        if (e_ != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e_, #x); }                             \
     } while (0)
 #define DCK(x)                                                                                                         \
     do {                                                                                                               \
         x;                                                                                                             \
         hipError_t e_ = hipGetLastError();                                                                             \
-        if (e_ != hipSuccess) return hip_fail(e_, #x);                                                                 \
+        if (e_ != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e_, #x); }                             \
     } while (0)
 
 } // namespace
@@ -217,11 +227,16 @@ int stedc_gpu(chase_hip_ctx* c, int n, const double* d_in, const double* e_in, d
     const size_t nn = (size_t)n * n;
     int nlev = 0;
     for (int s = nleaf; s > 1; s >>= 1) ++nlev;
-    double* blk = nullptr;
     const size_t dbl_count = 3 * nn + 8 * (size_t)n + (size_t)nlev * n + 64;
     const size_t int_count = 4 * (size_t)n + (size_t)nlev * n + 64;
     const size_t rot_count = (size_t)n + 8;
-    DCHK(hipMalloc((void**)&blk, dbl_count * sizeof(double) + int_count * sizeof(int) + rot_count * sizeof(Rot)));
+    // context-owned, grow-only (one hipMalloc for the life of the context instead of a hipMalloc + hipFree - a device-wide
+    // synchronisation - in every Rayleigh-Ritz call; separate from heevd_gpu's block, which is alive around this call)
+    {
+        const int rcb = c->ensure_buf(chase_hip_ctx::BUF_STEDC, dbl_count * sizeof(double) + int_count * sizeof(int) + rot_count * sizeof(Rot));
+        if (rcb) return rcb;
+    }
+    double* blk = (double*)c->bufs[chase_hip_ctx::BUF_STEDC];
     double* Q = blk; double* W = Q + nn; double* S = W + nn;
     double* zbuf = S + nn; double* dl = zbuf + n; double* zz = dl + n; double* mu = zz + n; double* lam = mu + n;
     double* zhat = lam + n; double* spare = zhat + n; double* zsgn_all = spare + 2 * (size_t)n;   // nlev * n
@@ -245,7 +260,7 @@ int stedc_gpu(chase_hip_ctx* c, int n, const double* d_in, const double* e_in, d
                 else {
                     for (int t = 0; t < s; ++t) { dd[t] = d[o + t]; ee[t] = (t + 1 < s) ? e[o + t] : 0.0; }
                     const int rc = host_stedc(s, dd.data(), ee.data(), ww.data(), Zl, s);
-                    if (rc) return rc;
+                    if (rc) { (void)hipStreamSynchronize(st); return rc; }
                     for (int t = 0; t < s; ++t) D[o + t] = ww[t];
                 }
                 DCHK(hipMemcpy2DAsync(Q + (size_t)o * n + o, (size_t)n * sizeof(double), Zl, (size_t)s * sizeof(double),
@@ -349,7 +364,7 @@ int stedc_gpu(chase_hip_ctx* c, int n, const double* d_in, const double* e_in, d
                 for (int t = 0; t < (int)defl.size(); ++t) { h_perm[o + m.k + t] = defl[t]; dnew[m.k + t] = D[defl[t]]; }
                 for (int t = m.k; t < nm; ++t) D[o + t] = dnew[t];   // D[o .. o+k) comes back from the device below
             }
-            if (h_rots.size() > rot_count) return set_error(CHASE_HIP_ENOTCONV, "stedc_gpu: rotation list overflow");
+            if (h_rots.size() > rot_count) { (void)hipStreamSynchronize(st); return set_error(CHASE_HIP_ENOTCONV, "stedc_gpu: rotation list overflow"); }
             DCHK(hipMemcpyAsync(perm_dev, h_perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
             DCHK(hipMemcpyAsync(dl, h_dl.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
             DCHK(hipMemcpyAsync(zz, h_zz.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
@@ -366,17 +381,17 @@ int stedc_gpu(chase_hip_ctx* c, int n, const double* d_in, const double* e_in, d
                 // W[o:o+nm, o+t] = Q[o:o+nm, perm[o+t]]
                 {
                     int e2 = copy_cols_indexed_range(st, Q + o, (long)n, W + o, (long)n, (long)nm, perm_dev + o, o, nm);
-                    if (e2) return hip_fail((hipError_t)e2, "stedc_gpu gather");
+                    if (e2) { (void)hipStreamSynchronize(st); return hip_fail((hipError_t)e2, "stedc_gpu gather"); }
                 }
                 DCK(hipLaunchKernelGGL(dc_secular_kernel, dim3((k + 3) / 4), dim3(256), 0, st, k, dl + o, zz + o, m.rho, org + o, mu + o, lam + o));
                 DCK(hipLaunchKernelGGL(dc_zhat_kernel, dim3((k + 3) / 4), dim3(256), 0, st, k, dl + o, zz + o, org + o, mu + o, zhat + o));
-                DCK(hipLaunchKernelGGL(dc_vectors_kernel, dim3(k), dim3(256), 0, st, k, dl + o, zhat + o, org + o, mu + o, S + (size_t)o * n + o, (long)n));
+                DCK(hipLaunchKernelGGL(dc_vectors_kernel, dim3(k), dim3(256), 0, st, k, dl + o, zhat + o, org + o, mu + o, S + (size_t)o * n + o, (long)n, lam + o));
                 const double one[2] = {1.0, 0.0}, zero[2] = {0.0, 0.0};
                 int gr = c->gemm(false, 'N', nm, k, k, one, W + (size_t)o * n + o, n, S + (size_t)o * n + o, n, zero, Q + (size_t)o * n + o, n);
-                if (gr) return gr;
+                if (gr) { (void)hipStreamSynchronize(st); return gr; }
                 if (k < nm) {
                     int e3 = copy2d(st, W + (size_t)(o + k) * n + o, (long)n, Q + (size_t)(o + k) * n + o, (long)n, (long)nm, nm - k);
-                    if (e3) return hip_fail((hipError_t)e3, "stedc_gpu deflated copy");
+                    if (e3) { (void)hipStreamSynchronize(st); return hip_fail((hipError_t)e3, "stedc_gpu deflated copy"); }
                 }
             }
             if (any) DCHK(hipMemcpyAsync(h_dl.data(), lam, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -396,13 +411,12 @@ int stedc_gpu(chase_hip_ctx* c, int n, const double* d_in, const double* e_in, d
         for (int t = 0; t < n; ++t) w_host[t] = D[p[t]] * orgnrm;
         DCHK(hipMemcpyAsync(perm_dev, p.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
         int e4 = copy_cols_indexed_range(st, Q, (long)n, Z, ldz, (long)n, perm_dev, 0, n);
-        if (e4) return hip_fail((hipError_t)e4, "stedc_gpu final order");
+        if (e4) { (void)hipStreamSynchronize(st); return hip_fail((hipError_t)e4, "stedc_gpu final order"); }
         DCHK(hipStreamSynchronize(st));
         return 0;
     };
     const int rc = body();
     hipStreamSynchronize(st);
-    hipFree(blk);
     if (dbg && rc == 0)
         fprintf(stderr, "stedc_gpu n=%d: %d leaves, %.2f ms\n", n, nleaf,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());

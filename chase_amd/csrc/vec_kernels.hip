@@ -14,7 +14,7 @@ int chase_hip_ctx::gemm(bool cplx, char opA, int m, int n, int k, const double* 
     const size_t need = std::max(chase_hip::gemm_f64_ws_need(cplx, opA, m, n, k, num_cu, gemm_min_rounds), (size_t)8 << 20);
     int rc = ensure_ws((need + ((size_t)32 << 20) - 1) & ~(((size_t)32 << 20) - 1));
     if (rc) return rc;
-    const int ph = (phase >= 0 && phase <= 2) ? phase : 0;
+    const int ph = (phase >= 0 && phase <= 3) ? phase : 0;
     int e = chase_hip::gemm_f64(stream, cplx, opA, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, (double*)ws, ws_bytes,
                                 num_cu, phase, device, &flops_exec[ph], gemm_min_rounds);
     if (e) return chase_hip::hip_fail((hipError_t)e, "gemm launch");

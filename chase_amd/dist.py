@@ -112,12 +112,21 @@ class Grid:
         self.transport = transport
         h = c_void_p()
         if transport == "rccl":
-            import torch.distributed as dist
+            # bootstrap (the reference broadcasts its ids over MPI, grid/mpiGrid2D.hpp:448-484): through the communicator
+            # the caller hands over - rank threads of one process (chase_amd.rank_threads.RankComm) or torch.distributed
+            if hasattr(pg, "all_gather_object"):
+                gather = pg.all_gather_object
+            else:
+                import torch.distributed as dist
+
+                def gather(obj):
+                    out = [None] * (nprow * npcol)
+                    dist.all_gather_object(out, obj)
+                    return out
             my_id = C.create_string_buffer(128)
             check(lib.chase_hip_rccl_unique_id(my_id), "rccl_unique_id")
-            ids = [None] * (nprow * npcol)
             if nprow * npcol > 1:
-                dist.all_gather_object(ids, bytes(my_id.raw))
+                ids = gather(bytes(my_id.raw))
             else:
                 ids = [bytes(my_id.raw)]
             row_leader = self.myrow                         # (myrow, 0)
@@ -125,9 +134,8 @@ class Grid:
             # a rank may lead both its row and its column group (rank 0): use distinct ids -> generate a second one
             my_id2 = C.create_string_buffer(128)
             check(lib.chase_hip_rccl_unique_id(my_id2), "rccl_unique_id")
-            ids2 = [None] * (nprow * npcol)
             if nprow * npcol > 1:
-                dist.all_gather_object(ids2, bytes(my_id2.raw))
+                ids2 = gather(bytes(my_id2.raw))
             else:
                 ids2 = [bytes(my_id2.raw)]
             check(lib.chase_hip_grid_create_rccl(C.byref(h), ctx.h, nprow, npcol, rank, ids[row_leader],
@@ -137,7 +145,7 @@ class Grid:
             # make_process_groups (ranks = processes, payloads through gloo) or any object with
             # allreduce(group, array) / bcast(group, array, root) / sendrecv(group, send, peer_send, recv, peer_recv)
             # working in place on float64 numpy views of the pinned staging buffer (ranks = threads of one process,
-            # tests/rank_threads.py)
+            # chase_amd/rank_threads.py)
             fabric = pg if hasattr(pg, "allreduce") else (GlooFabric(pg, nprow, npcol, rank) if pg is not None else None)
             self.fabric = fabric
 

@@ -1,7 +1,10 @@
-"""One rank of `bench.py --gpus N` (N > 1; also the 1x1-grid development runs): one process per GPU, 2D grid of the
-reference (nprow x npcol with nprow >= npcol: 2x1, 2x2, 4x2; grid/mpiGrid2D.hpp), RCCL row/column all-reduces over xGMI,
-the SAME workload as the single-GPU line (strong scaling).  torch.distributed (gloo over MASTER_ADDR) is used only for
-bootstrap (unique-id exchange), barriers and the max / sum over ranks of the timing figures.
+"""The ranks of `bench.py --gpus N` (N > 1; also the 1x1-grid development runs): 2D grid of the reference (nprow x npcol with
+nprow >= npcol: 2x1, 2x2, 4x2; grid/mpiGrid2D.hpp), RCCL row/column all-reduces over xGMI, the SAME workload as the
+single-GPU line (strong scaling).  Two forms: one PROCESS per GPU (run_distributed: torch.distributed / gloo over
+MASTER_ADDR only for bootstrap - unique-id exchange -, barriers and the max / sum over ranks of the timing figures) and one
+THREAD per GPU inside one process (run_threads).  Either way a run first PROVES its transport (transport_proof: bus
+bandwidth of a 256 MB all-reduce per communicator, in the JSON line) and exits non-zero instead of printing a scaling
+number when a communicator is not on xGMI.
 
 A rank whose communicator cannot be created exits non-zero: there is no fallback transport in a measured run (the
 host-callback transport exists for tests on a single-GPU box: CHASE_HIP_TRANSPORT=host, labelled in config.workload)."""
@@ -70,57 +73,77 @@ def comm_probe(ctx, grid, dH, m_loc, n_loc, cplx, nevex, panel=256, reps=5):
     return out
 
 
-def run_distributed(args):
-    import torch
-    import torch.distributed as dist
-    from .capi import Context, gemm_counters
+def transport_proof(ctx, grid, comm, nbytes=256 << 20, reps=3):
+    """Before any solve: one 256 MB all-reduce per communicator, timed on its own.  A size >= 2 RCCL group that moves less
+    than MIN_BUSBW_GBPS is not running over xGMI peer-to-peer (host-staged rings over PCIe reach 10-25 GB/s, one xGMI link
+    ~50 GB/s per direction and the 7 links of a device several times that) - the run then refuses to print a scaling
+    number.  Returns (record, ok) identical on every rank."""
+    from .capi import lib, check
+    from .dist import ROW, COL
+    rec, ok = {"bytes": nbytes, "reps": reps, "min_busbw_GBps_required": MIN_BUSBW_GBPS}, True
+    is_rccl = grid.transport_info()[0]
+    count = nbytes // 8
+    for name, group, size in (("row_group", ROW, grid.npcol), ("col_group", COL, grid.nprow)):
+        if not lib.chase_hip_grid_group_active(grid.h, group):
+            continue
+        buf = ctx.empty((count,), np.float64)
+        check(lib.chase_hip_memset(ctx.h, buf.ptr, 0, nbytes), "memset")
+        check(lib.chase_hip_grid_allreduce(grid.h, group, buf.ptr, count, 0), "allreduce")      # connections, first touch
+        ctx.sync()
+        comm.barrier()
+        ctx.timer_start()
+        for _ in range(reps):
+            check(lib.chase_hip_grid_allreduce(grid.h, group, buf.ptr, count, 0), "allreduce")
+        ms = ctx.timer_stop() / reps
+        buf.free()
+        ms = comm.allreduce_max([ms])[0]
+        busbw = nbytes * 2.0 * (size - 1) / size / (ms * 1e-3) / 1e9
+        rec[name] = {"ranks": size, "ms": ms, "algbw_GBps": nbytes / (ms * 1e-3) / 1e9, "busbw_GBps": busbw}
+        if is_rccl and size >= 2 and busbw < MIN_BUSBW_GBPS:
+            ok = False
+    rec["ok"] = ok
+    return rec, ok
+
+
+MIN_BUSBW_GBPS = float(os.environ.get("CHASE_HIP_MIN_BUSBW_GBPS", "40"))
+EXIT_TRANSPORT_TOO_SLOW = 5
+
+
+class TransportTooSlow(RuntimeError):
+    pass
+
+
+def run_rank(args, comm, ctx, grid, mode):
+    """One rank of the multi-GPU bench on an established context + grid; `comm` carries bootstrap, barriers and the max / sum
+    over ranks of the timing figures (chase_amd.rank_threads.RankComm or GlooComm).  Rank 0 returns the result record."""
+    from .capi import gemm_counters
     from . import dist as cd
     import bench as B
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    dist.init_process_group("gloo")
+    rank, world = comm.rank, comm.world
     workload = args.workload or B.DEFAULT_WORKLOAD
     N, cplx, nev, nex = B.WORKLOADS[workload]
     if args.n:
         N = args.n
     nevex = nev + nex
-    nprow, npcol = cd.grid_shape(world)
-    myrow, mycol = cd.coords_of(rank, nprow)
-    transport = os.environ.get("CHASE_HIP_TRANSPORT", "rccl")
-    # health check BEFORE anybody enters ncclCommInitRank (which blocks until all members arrive): every rank must have
-    # its device context; a rank without one makes ALL ranks leave with an error instead of leaving the others hanging
-    ctx, err = None, ""
-    try:
-        ndev = torch.cuda.device_count()
-        ctx = Context(local_rank % max(ndev, 1))
-    except Exception as e:
-        err = str(e)
-    okflag = torch.tensor([1 if ctx is not None else 0], dtype=torch.int32)
-    dist.all_reduce(okflag, op=dist.ReduceOp.MIN)
-    if int(okflag[0]) == 0:
-        print(f"bench rank {rank}: no usable device context ({err or 'another rank failed'})", file=sys.stderr, flush=True)
-        dist.destroy_process_group()
-        sys.exit(3)
-    pg = cd.make_process_groups(nprow, npcol)
-    try:
-        grid = cd.Grid(ctx, nprow, npcol, rank, transport=transport, pg=pg)
-    except Exception as e:
-        # no silent fallback: a run that would measure PCIe + gloo instead of RCCL over xGMI must not print a value
-        print(f"bench rank {rank}: {transport} grid creation failed: {e}", file=sys.stderr, flush=True)
-        os._exit(4)
+    nprow, npcol = grid.nprow, grid.npcol
+    myrow, mycol = grid.myrow, grid.mycol
     is_rccl, rccl_row, rccl_col = grid.transport_info()
     # one line per rank for the audit of a multi-GPU run: which physical device, what the runtime was allowed to see, and
     # how many ranks RCCL itself counts in this rank's row / column communicator
-    print(f"bench rank {rank}/{world}: grid ({myrow},{mycol}) of {nprow}x{npcol}, device bus id {ctx.bus_id()}, "
-          f"bound to ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES', '<all>')} "
-          f"({torch.cuda.device_count()} visible), transport {'rccl' if is_rccl else 'host'}, "
-          f"ncclCommCount row {rccl_row} col {rccl_col}", file=sys.stderr, flush=True)
+    print(f"bench rank {rank}/{world} [{mode}]: grid ({myrow},{mycol}) of {nprow}x{npcol}, ordinal {ctx.device}, device bus id "
+          f"{ctx.bus_id()}, ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES', '<all>')}, transport "
+          f"{'rccl' if is_rccl else 'host'}, ncclCommCount row {rccl_row} col {rccl_col}", file=sys.stderr, flush=True)
     grid.set_profiling(True)
     # RCCL prints a version banner through C stdio at communicator creation; push it out NOW on every rank so that the
     # JSON line rank 0 prints at the end is the last line of the job's stdout
     ctypes.CDLL(None).fflush(None)
+    proof, proof_ok = transport_proof(ctx, grid, comm)
+    if rank == 0:
+        print("bench: transport proof " + json.dumps(proof), file=sys.stderr, flush=True)
+    if not proof_ok:
+        raise TransportTooSlow("a communicator moves less than %.0f GB/s (bus bandwidth of a 256 MB all-reduce): RCCL is not "
+                               "on xGMI peer-to-peer in mode '%s' - %s" % (MIN_BUSBW_GBPS, mode, json.dumps(proof)))
     mb = nb = args.block_cyclic if args.block_cyclic >= 0 else B.DEFAULT_BLOCK_CYCLIC.get(workload, 0)
     rl, cl = cd.Layout(N, mb, nprow), cd.Layout(N, nb, npcol)
     pseudo = workload in B.PSEUDO_WORKLOADS
@@ -141,16 +164,12 @@ def run_distributed(args):
         return {"filter_ms": s.get("filter_ms"), "hemm_calls": s.get("hemm_calls"), "reused": s.get("hemm_reused_vecs"),
                 "model": model, "exec": execd, "gemms": calls, "exposed_ms": exposed_ms, "waits": waits}
 
-    timer = B.StepTimer(args.steps, args.warmup, ctx.sync, dist.barrier, snapshot)
+    timer = B.StepTimer(args.steps, args.warmup, ctx.sync, comm.barrier, snapshot, progress=(rank == 0))
     complete, last = B.run_timed_solves(s, timer, nev, lambda: (s.ritzv[:nev].copy(), s.resid()[:nev].copy()))
     wall_loc = timer.t1 - timer.t0
     # MAX over ranks of the wall time, the filter time and the exposed communication; SUM of the kernel-side flop books
-    t = torch.tensor([wall_loc, timer.diff("filter_ms") * 1e-3, timer.diff("exposed_ms")], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall, filt_s, exposed_ms = float(t[0]), float(t[1]), float(t[2])
-    f = torch.tensor([timer.diff("model"), timer.diff("exec")], dtype=torch.float64)
-    dist.all_reduce(f, op=dist.ReduceOp.SUM)
-    model_flops, exec_flops = float(f[0]), float(f[1])
+    wall, filt_s, exposed_ms = comm.allreduce_max([wall_loc, timer.diff("filter_ms") * 1e-3, timer.diff("exposed_ms")])
+    model_flops, exec_flops = comm.allreduce_sum([timer.diff("model"), timer.diff("exec")])
     calls = int(timer.diff("hemm_calls"))
     reused = int(timer.diff("reused"))
     hemm_vecs = timer.filtered_timed - reused
@@ -164,19 +183,17 @@ def run_distributed(args):
     # independent residuals of the last solve's eigenvectors (fresh four-product H V, redistribution, all-reduce over the
     # row group: mpi/residuals.hpp:61-107 as it stands), outside the timed region; collective
     resid_re = s.recompute_residuals(nev, lam)
-    ok = bool(np.max(resid) < 1e-8 and np.max(resid_re) < 1e-8 and (spec is None or spec["ok"]))
+    tol = s.get("tol")
+    ok = B.converged_ok(lam, resid, resid_re, tol, spec)
     st = complete[-1]
     solve_s = float(np.mean([c["t_all"] for c in complete]))
     tot = snapshot()
-    tw = torch.tensor([tot["model"], tot["exec"]], dtype=torch.float64)
-    dist.all_reduce(tw, op=dist.ReduceOp.SUM)
-    tm = torch.tensor([tot["filter_ms"]], dtype=torch.float64)
-    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-    tot["model"], tot["exec"], tot["filter_ms"] = float(tw[0]), float(tw[1]), float(tm[0])
+    tot["model"], tot["exec"] = comm.allreduce_sum([tot["model"], tot["exec"]])
+    tot["filter_ms"] = comm.allreduce_max([tot["filter_ms"]])[0]
     probe = None
     # (the host-callback test transport runs it only on request: CHASE_HIP_PROBE_HOST=1, to exercise the multi-rank code path)
     if (is_rccl or os.environ.get("CHASE_HIP_PROBE_HOST") == "1") and not pseudo and not getattr(args, "no_probe", False):
-        dist.barrier()
+        comm.barrier()
         probe = comm_probe(ctx, grid, dH, rl.count(myrow), cl.count(mycol), cplx, nevex)
     out = None
     if rank == 0:
@@ -190,13 +207,15 @@ def run_distributed(args):
                                       else "perturbed Clement-type Hermitian (x100/N)") + f" N={N} "
                                    f"{'complex' if cplx else 'real'} fp64, nev={nev} nex={nex}, tol 1e-10, deg 20 opt, "
                                    f"{nprow}x{npcol} {'block-cyclic nb=%d' % nb if nb else 'block'} grid, "
-                                   + ("RCCL over xGMI" if is_rccl else "host-callback (gloo) TEST transport - not a measurement of RCCL")
+                                   + ("RCCL over xGMI" if is_rccl else "host-callback TEST transport - not a measurement of RCCL")
+                                   + f", ranks = {mode}"
                                    + "; step = one outer iteration (filter+QR+RR+residuals+locking), solves back to back",
                        "N": N, "nev": nev, "nex": nex, "grid": f"{nprow}x{npcol}", "step": "outer iteration",
-                       "transport": "rccl" if is_rccl else "host"},
+                       "transport": "rccl" if is_rccl else "host", "ranks": mode},
             "eigenpairs_per_sec": nev / solve_s, "solve_seconds": solve_s, "complete_solves": len(complete),
             "pct_fp64_mfma_peak": 100.0 * exec_flops / filt_s / 1e12 / world / B.FP64_MFMA_PEAK_TFLOPS,
             "converged": ok, "max_resid": float(np.max(resid)), "max_resid_recomputed": float(np.max(resid_re)),
+            "residuals_rechecked_on_the_tolerance": int(s.get("resd_rechecked")),
             "spectrum_check": spec,
             "iterations_per_solve": st["iterations"], "filtered_vecs_per_solve": st["filtered_vecs"],
             "timed": {"filtered_vecs": timer.filtered_timed, "hemm_vecs": hemm_vecs, "first_step_vecs_from_rr": reused,
@@ -204,10 +223,12 @@ def run_distributed(args):
                       "iterations": [{"solve": a, "iteration": b, "filtered_vecs": c, "seconds": d}
                                      for a, b, c, d in timer.per_iter]},
             "phase_seconds_last_complete_solve": {k: st[k] for k in B.PHASES},
-            # diagnosis of the multi-GPU run: what RCCL itself reports, and how long the compute stream sat waiting for a
-            # collective with nothing else to run (bracketing events around every wait on the communication stream)
+            # diagnosis of the multi-GPU run: what RCCL itself reports, what the communicators move on their own, and how
+            # long the compute stream sat waiting for a collective with nothing else to run (bracketing events around every
+            # wait on the communication stream)
             "ranks_seen_by_rccl": {"row_communicator": rccl_row, "col_communicator": rccl_col,
                                    "grid": rccl_row * rccl_col if is_rccl else None},
+            "transport_proof": proof,
             "comm_exposed_ms": exposed_ms, "comm_exposed_frac_of_wall": exposed_ms * 1e-3 / wall,
             "comm_waits": int(timer.diff("waits")),
             "roofline": B.roofline_object(model_flops, exec_flops, filt_s, calls, world,
@@ -216,10 +237,100 @@ def run_distributed(args):
         out["roofline"]["whole_run"] = B.whole_run_object(tot, world)
         out["comm_probe"] = probe
     s.close()
-    grid.close()
     del dH
+    return out
+
+
+def run_distributed(args, probe_only=False):
+    """Process-per-GPU form (the contract's launch: torch.distributed.run, or bench.py's own spawn_ranks): this process is
+    one rank; gloo over MASTER_ADDR carries the bootstrap and the barriers."""
+    import torch
+    import torch.distributed as dist
+    from .capi import Context
+    from . import dist as cd
+    from .rank_threads import GlooComm
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    dist.init_process_group("gloo")
+    comm = GlooComm()
+    nprow, npcol = cd.grid_shape(world)
+    transport = os.environ.get("CHASE_HIP_TRANSPORT", "rccl")
+    # health check BEFORE anybody enters ncclCommInitRank (which blocks until all members arrive): every rank must have
+    # its device context; a rank without one makes ALL ranks leave with an error instead of leaving the others hanging
+    ctx, err = None, ""
+    try:
+        ndev = torch.cuda.device_count()
+        ctx = Context(local_rank % max(ndev, 1))
+    except Exception as e:
+        err = str(e)
+    if comm.allreduce_min([1 if ctx is not None else 0])[0] == 0:
+        print(f"bench rank {rank}: no usable device context ({err or 'another rank failed'})", file=sys.stderr, flush=True)
+        dist.destroy_process_group()
+        sys.exit(3)
+    try:
+        pg = cd.make_process_groups(nprow, npcol) if transport != "rccl" else comm
+        grid = cd.Grid(ctx, nprow, npcol, rank, transport=transport, pg=pg)
+    except Exception as e:
+        # no silent fallback: a run that would measure PCIe + gloo instead of RCCL over xGMI must not print a value
+        print(f"bench rank {rank}: {transport} grid creation failed: {e}", file=sys.stderr, flush=True)
+        os._exit(4)
+    mode = "processes" + (", all devices visible" if "CHASE_HIP_BOUND_DEVICE" not in os.environ else ", one visible device each")
+    if probe_only:
+        # child of bench.py's mode selection: context, communicators and the transport proof, then out - status 0 = usable
+        proof, ok = transport_proof(ctx, grid, comm)
+        if rank == 0:
+            print(f"bench probe [{mode}]: " + json.dumps(proof), file=sys.stderr, flush=True)
+        grid.close()
+        ctx.close()
+        ctypes.CDLL(None).fflush(None)
+        dist.barrier()
+        dist.destroy_process_group()
+        os._exit(0 if ok else EXIT_TRANSPORT_TOO_SLOW)
+    try:
+        out = run_rank(args, comm, ctx, grid, mode)
+    except TransportTooSlow as e:
+        print(f"bench rank {rank}: {e}", file=sys.stderr, flush=True)
+        ctypes.CDLL(None).fflush(None)
+        os._exit(EXIT_TRANSPORT_TOO_SLOW)
+    grid.close()
     ctx.close()
     ctypes.CDLL(None).fflush(None)
     dist.barrier()
     dist.destroy_process_group()
     return out
+
+
+def run_threads(args, nranks):
+    """`bench.py --gpus N --ranks threads`: ONE process, one thread per GPU.  Thread r opens device r (r modulo
+    the visible devices, so that the launcher logic can be rehearsed with several threads on one GPU over the host
+    transport), ncclCommInitRank runs from the N threads (ctypes drops the GIL around every library call), the bootstrap
+    and the barriers stay inside the process.  No visibility tricks, no IPC handles, one process per card."""
+    import torch
+    from . import dist as cd
+    from .rank_threads import run_ranks
+
+    nprow, npcol = cd.grid_shape(nranks)
+    transport = os.environ.get("CHASE_HIP_TRANSPORT", "rccl")
+    ndev = max(torch.cuda.device_count(), 1)
+    if transport == "rccl" and nranks > ndev:
+        raise SystemExit(f"bench: --ranks threads needs one GPU per rank for RCCL ({nranks} ranks, {ndev} devices visible)")
+    result = {}
+
+    def body(ctx, grid, comm):
+        out = run_rank(args, comm, ctx, grid, "threads of one process")
+        if comm.rank == 0:
+            result["out"] = out
+
+    try:
+        run_ranks(nprow, npcol, body, device=lambda r: r % ndev, transport=transport)
+    except AssertionError as e:
+        cause = e.__cause__
+        if isinstance(cause, TransportTooSlow):
+            print(f"bench: {cause}", file=sys.stderr, flush=True)
+            ctypes.CDLL(None).fflush(None)
+            os._exit(EXIT_TRANSPORT_TOO_SLOW)
+        raise
+    ctypes.CDLL(None).fflush(None)
+    return result.get("out")

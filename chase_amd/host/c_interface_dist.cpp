@@ -23,7 +23,11 @@
 #include <complex>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/chase_c_interface.h"
 #include "../../include/chase_hip.h"
@@ -61,11 +65,50 @@ struct DistSlot {
         V = nullptr; ritzv = nullptr;
     }
 };
-// one distributed solver per type like the reference's static members (chase_c_interface.cpp:905-1290) - per calling
-// THREAD: a rank is a thread here when one process drives several GPUs (one thread per device), and the whole process when
-// the application is an ordinary single-threaded MPI rank, which is the reference's case
-thread_local DistSlot g_pd, g_pz;
-thread_local chase_hip_ctx* g_next_ctx = nullptr;           // set by chase_hip_cshim_use_ctx for the next init
+// One distributed solver per type like the reference's static members (chase_c_interface.cpp:905-1290): PROCESS-wide, so an
+// application may call p?chase_init_ on one thread and p?chase_ / get_eigenpairs / finalize on another (OpenMP regions, a
+// host language's worker threads, MPI_THREAD_MULTIPLE) exactly as with the reference.  Only when a SECOND thread
+// initialises a solver of the same type while the first one's is alive - several ranks of a grid living as threads of one
+// process, one per GPU - does that thread get a slot of its own, which its later calls find by thread id.
+struct SlotTable {
+    std::mutex mu;
+    DistSlot global;
+    std::thread::id owner{};
+    bool claimed = false;
+    std::map<std::thread::id, std::unique_ptr<DistSlot>> extra;
+    DistSlot& for_init()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        const auto me = std::this_thread::get_id();
+        auto it = extra.find(me);
+        if (it != extra.end()) return *it->second;
+        if (!claimed || owner == me) { claimed = true; owner = me; return global; }
+        auto& up = extra[me];
+        up.reset(new DistSlot());
+        return *up;
+    }
+    DistSlot& current()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = extra.find(std::this_thread::get_id());
+        return it != extra.end() ? *it->second : global;
+    }
+    void finalize()
+    {
+        std::unique_ptr<DistSlot> mine;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = extra.find(std::this_thread::get_id());
+            if (it != extra.end()) { mine = std::move(it->second); extra.erase(it); }
+            else claimed = false;
+        }
+        if (mine) mine->clear(); else global.clear();
+    }
+};
+SlotTable g_td, g_tz;
+#define g_pd (g_td.current())
+#define g_pz (g_tz.current())
+thread_local chase_hip_ctx* g_next_ctx = nullptr;           // set by chase_hip_cshim_use_ctx for the next init ON THIS THREAD
 thread_local bool g_next_own = false;
 
 // mbsize / nbsize == 0: block layout (block length rule of the reference, distMatrix.hpp:2000-2039)
@@ -178,61 +221,61 @@ chase_hip_solver* chase_hip_cshim_dist_solver(int cplx) { return cplx ? g_pz.s :
 void pdchase_init_hip_(int* N, int* nev, int* nex, int* m, int* n, double* H, int* ldh, double* V, double* ritzv,
                        chase_hip_grid* grid, int* init)
 {
-    init_dist(g_pd, 0, 0, *N, *nev, *nex, 0, 0, *m, *n, H, *ldh, V, ritzv, 0, 0, grid, init);
+    init_dist(g_td.for_init(), 0, 0, *N, *nev, *nex, 0, 0, *m, *n, H, *ldh, V, ritzv, 0, 0, grid, init);
 }
 void pdchase_init_internal_hip_(int* N, int* nev, int* nex, int* m, int* n, double* H, int* ldh, chase_hip_grid* grid, int* init)
 {
-    init_dist(g_pd, 0, 0, *N, *nev, *nex, 0, 0, *m, *n, H, *ldh, nullptr, nullptr, 0, 0, grid, init);
+    init_dist(g_td.for_init(), 0, 0, *N, *nev, *nex, 0, 0, *m, *n, H, *ldh, nullptr, nullptr, 0, 0, grid, init);
 }
 void pzchase_init_hip_(int* N, int* nev, int* nex, int* m, int* n, void* H, int* ldh, void* V, double* ritzv,
                        chase_hip_grid* grid, int* init)
 {
-    init_dist(g_pz, 1, 0, *N, *nev, *nex, 0, 0, *m, *n, H, *ldh, V, ritzv, 0, 0, grid, init);
+    init_dist(g_tz.for_init(), 1, 0, *N, *nev, *nex, 0, 0, *m, *n, H, *ldh, V, ritzv, 0, 0, grid, init);
 }
 void pzchase_init_internal_hip_(int* N, int* nev, int* nex, int* m, int* n, void* H, int* ldh, chase_hip_grid* grid, int* init)
 {
-    init_dist(g_pz, 1, 0, *N, *nev, *nex, 0, 0, *m, *n, H, *ldh, nullptr, nullptr, 0, 0, grid, init);
+    init_dist(g_tz.for_init(), 1, 0, *N, *nev, *nex, 0, 0, *m, *n, H, *ldh, nullptr, nullptr, 0, 0, grid, init);
 }
 void pzchase_init_pseudo_hip_(int* N, int* nev, int* nex, int* m, int* n, void* H, int* ldh, void* V, double* ritzv,
                               chase_hip_grid* grid, int* init)
 {
-    init_dist(g_pz, 1, 1, *N, *nev, *nex, 0, 0, *m, *n, H, *ldh, V, ritzv, 0, 0, grid, init);
+    init_dist(g_tz.for_init(), 1, 1, *N, *nev, *nex, 0, 0, *m, *n, H, *ldh, V, ritzv, 0, 0, grid, init);
 }
 void pzchase_init_pseudo_internal_hip_(int* N, int* nev, int* nex, int* m, int* n, void* H, int* ldh, chase_hip_grid* grid,
                                        int* init)
 {
-    init_dist(g_pz, 1, 1, *N, *nev, *nex, 0, 0, *m, *n, H, *ldh, nullptr, nullptr, 0, 0, grid, init);
+    init_dist(g_tz.for_init(), 1, 1, *N, *nev, *nex, 0, 0, *m, *n, H, *ldh, nullptr, nullptr, 0, 0, grid, init);
 }
 /* ---- block-cyclic layout (interface/chase_c_interface.h:61-124) ------------------------------------------------------ */
 void pdchase_init_blockcyclic_hip_(int* N, int* nev, int* nex, int* mbsize, int* nbsize, double* H, int* ldh, double* V,
                                    double* ritzv, int* irsrc, int* icsrc, chase_hip_grid* grid, int* init)
 {
-    init_dist(g_pd, 0, 0, *N, *nev, *nex, *mbsize, *nbsize, -1, -1, H, *ldh, V, ritzv, *irsrc, *icsrc, grid, init);
+    init_dist(g_td.for_init(), 0, 0, *N, *nev, *nex, *mbsize, *nbsize, -1, -1, H, *ldh, V, ritzv, *irsrc, *icsrc, grid, init);
 }
 void pdchase_init_blockcyclic_internal_hip_(int* N, int* nev, int* nex, int* mbsize, int* nbsize, double* H, int* ldh,
                                             int* irsrc, int* icsrc, chase_hip_grid* grid, int* init)
 {
-    init_dist(g_pd, 0, 0, *N, *nev, *nex, *mbsize, *nbsize, -1, -1, H, *ldh, nullptr, nullptr, *irsrc, *icsrc, grid, init);
+    init_dist(g_td.for_init(), 0, 0, *N, *nev, *nex, *mbsize, *nbsize, -1, -1, H, *ldh, nullptr, nullptr, *irsrc, *icsrc, grid, init);
 }
 void pzchase_init_blockcyclic_hip_(int* N, int* nev, int* nex, int* mbsize, int* nbsize, void* H, int* ldh, void* V,
                                    double* ritzv, int* irsrc, int* icsrc, chase_hip_grid* grid, int* init)
 {
-    init_dist(g_pz, 1, 0, *N, *nev, *nex, *mbsize, *nbsize, -1, -1, H, *ldh, V, ritzv, *irsrc, *icsrc, grid, init);
+    init_dist(g_tz.for_init(), 1, 0, *N, *nev, *nex, *mbsize, *nbsize, -1, -1, H, *ldh, V, ritzv, *irsrc, *icsrc, grid, init);
 }
 void pzchase_init_blockcyclic_internal_hip_(int* N, int* nev, int* nex, int* mbsize, int* nbsize, void* H, int* ldh,
                                             int* irsrc, int* icsrc, chase_hip_grid* grid, int* init)
 {
-    init_dist(g_pz, 1, 0, *N, *nev, *nex, *mbsize, *nbsize, -1, -1, H, *ldh, nullptr, nullptr, *irsrc, *icsrc, grid, init);
+    init_dist(g_tz.for_init(), 1, 0, *N, *nev, *nex, *mbsize, *nbsize, -1, -1, H, *ldh, nullptr, nullptr, *irsrc, *icsrc, grid, init);
 }
 void pzchase_init_pseudo_blockcyclic_hip_(int* N, int* nev, int* nex, int* mbsize, int* nbsize, void* H, int* ldh, void* V,
                                           double* ritzv, int* irsrc, int* icsrc, chase_hip_grid* grid, int* init)
 {
-    init_dist(g_pz, 1, 1, *N, *nev, *nex, *mbsize, *nbsize, -1, -1, H, *ldh, V, ritzv, *irsrc, *icsrc, grid, init);
+    init_dist(g_tz.for_init(), 1, 1, *N, *nev, *nex, *mbsize, *nbsize, -1, -1, H, *ldh, V, ritzv, *irsrc, *icsrc, grid, init);
 }
 void pzchase_init_pseudo_blockcyclic_internal_hip_(int* N, int* nev, int* nex, int* mbsize, int* nbsize, void* H, int* ldh,
                                                    int* irsrc, int* icsrc, chase_hip_grid* grid, int* init)
 {
-    init_dist(g_pz, 1, 1, *N, *nev, *nex, *mbsize, *nbsize, -1, -1, H, *ldh, nullptr, nullptr, *irsrc, *icsrc, grid, init);
+    init_dist(g_tz.for_init(), 1, 1, *N, *nev, *nex, *mbsize, *nbsize, -1, -1, H, *ldh, nullptr, nullptr, *irsrc, *icsrc, grid, init);
 }
 
 /* ---- after init: the reference's names unchanged --------------------------------------------------------------------- */
@@ -240,8 +283,8 @@ void pdchase_(int* deg, double* tol, char* mode, char* opt, char* qr) { solve_di
 void pzchase_(int* deg, double* tol, char* mode, char* opt, char* qr) { solve_dist(g_pz, *deg, *tol, *mode, *opt, *qr); }
 void pdchase_get_eigenpairs_(double* LEigsV, int* ld, double* ritzv) { if (ld) get_pairs_dist(g_pd, LEigsV, *ld, ritzv); }
 void pzchase_get_eigenpairs_(void* LEigsV, int* ld, double* ritzv) { if (ld) get_pairs_dist(g_pz, LEigsV, *ld, ritzv); }
-void pdchase_finalize_(int* flag) { g_pd.clear(); if (flag) *flag = 0; }
-void pzchase_finalize_(int* flag) { g_pz.clear(); if (flag) *flag = 0; }
+void pdchase_finalize_(int* flag) { g_td.finalize(); if (flag) *flag = 0; }
+void pzchase_finalize_(int* flag) { g_tz.finalize(); if (flag) *flag = 0; }
 void pdchase_readHam_(const char* filename) { ham_io(g_pd, filename, true); }
 void pzchase_readHam_(const char* filename) { ham_io(g_pz, filename, true); }
 void pdchase_wrtHam_(const char* filename) { ham_io(g_pd, filename, false); }

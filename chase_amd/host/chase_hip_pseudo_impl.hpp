@@ -242,7 +242,7 @@ public:
         const std::size_t sub = nevex_ - locked_;
         T* V = dV1_ + locked_ * N_;
         T* W = dV2_ + locked_ * N_;
-        chase_hip_ctx_set_phase(ctx_, 2);
+        chase_hip_ctx_set_phase(ctx_, 3);                     // the residuals the convergence test reads: four products
         gemm('N', N_, sub, N_, T(1), dH_, ldd_h_, V, N_, T(0), W, N_);
         chase_hip_ctx_set_phase(ctx_, 0);
         hip_ok(chase_hip_resid_norms(ctx_, CP, (int)N_, (int)sub, W, (long)N_, V, (long)N_, ritzv, resd, 0), "resid");
@@ -253,7 +253,7 @@ public:
     {
         if (ncols > 2 * nevex_) throw std::invalid_argument("recompute_residuals: more columns than the Impl holds");
         flush_swaps();
-        chase_hip_ctx_set_phase(ctx_, 2);
+        chase_hip_ctx_set_phase(ctx_, 3);
         gemm('N', N_, ncols, N_, T(1), dH_, ldd_h_, dV1_, N_, T(0), dV2_, N_);
         chase_hip_ctx_set_phase(ctx_, 0);
         hip_ok(chase_hip_resid_norms(ctx_, CP, (int)N_, (int)ncols, dV2_, (long)N_, dV1_, (long)N_, lambda, out, 0), "resid");

@@ -312,20 +312,21 @@ public:
     {
         flush_swaps(); sync_comm();
         const std::size_t c0 = locked_;
-        // The reference re-broadcasts V inside the row group here so that the replicas over the grid columns are bitwise
-        // equal (pchase_gpu.hpp:1631-1633; 0.67 GB per call at config 4).  Not needed for agreement: every V the filter
-        // produces comes out of an all-reduce over that very row group (identical bits on its members), the Ritz pairs,
-        // potrf info, residuals and bounds are agreed explicitly (agree_vector / agree_max), and what a QR pass may leave
-        // between the replicas - last-bit differences from the two column groups' separate Gram all-reduces - is erased by
-        // the next filter step's row-group all-reduce.  CHASE_HIP_RR_RESYNC=1 restores the broadcast (debugging).
-        static const bool resync = [] { const char* e = std::getenv("CHASE_HIP_RR_RESYNC"); return e && std::atoi(e) != 0; }();
-        if (resync) coll(chase_hip_grid_bcast(grid_, CHASE_HIP_ROW, dV1_ + c0 * m_, m_ * block * E, 0, 0));
+        // Like the reference (pchase_gpu.hpp:1631-1633), V is re-broadcast inside the row group so that the replicas over the
+        // grid columns are bitwise equal when Rayleigh-Ritz starts: QR runs separately in every column group, and two column
+        // communicators may sum their Gram matrices in different orders - a last-bit difference that CholQR2 / shifted CholQR
+        // amplify by cond(V) eps.  Columns that get locked right after this step are never filtered again, so nothing later
+        // would erase it (round 3 dropped the broadcast; the advisor's finding).  0.67 GB inside a 2-GPU row group per call at
+        // config 4, a few ms over xGMI.  CHASE_HIP_RR_RESYNC=0 skips it (single-column grids have nothing to agree).
+        static const bool resync = [] { const char* e = std::getenv("CHASE_HIP_RR_RESYNC"); return e ? std::atoi(e) != 0 : true; }();
+        if (resync && npcol_ > 1) coll(chase_hip_grid_bcast(grid_, CHASE_HIP_ROW, dV1_ + c0 * m_, m_ * block * E, 0, 0));
         hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)block, dV1_ + c0 * m_, (long)m_, dV2_ + c0 * m_, (long)m_), "lacpy");
         chase_hip_ctx_set_phase(ctx_, 2);                                    // H-times-block product outside the filter
         hemm_dir(true, c0, block, T(1), T(0), false);                        // W1 = H^H V1 (row-type), all-reduced
         chase_hip_ctx_set_phase(ctx_, 0);
         redistribute_c2r(dV2_ + c0 * m_, dW2_ + c0 * n_, block);             // W2 = V2 in the row-type layout
-        gemm('C', block, block, n_, T(1), dW2_ + c0 * n_, n_, dW1_ + c0 * n_, n_, T(0), dA_, block);
+        // A = V^H (H V), Hermitian: only the upper block trapezoid is multiplied, packed and summed over the row group
+        hip_ok(chase_hip_herkx(ctx_, CP, (int)block, (int)n_, dW2_ + c0 * n_, (long)n_, dW1_ + c0 * n_, (long)n_, dA_, (long)block, 0), "herkx");
         allreduce_packed_upper(dA_, block, CHASE_HIP_ROW);
         hip_ok(chase_hip_heevd(ctx_, CP, (int)block, dA_, (long)block, ritzv), "heevd");
         agree_vector(ritzv, block, dA_, block * block);                      // identical Ritz pairs on every rank
@@ -368,8 +369,51 @@ public:
         hip_ok(chase_hip_memcpy_d2h(ctx_, resd, d, sub * sizeof(double)), "d2h");
         for (std::size_t i = 0; i < sub; ++i) resd[i] = std::sqrt(resd[i]);
         agree_vector(resd, sub, nullptr, 0);
+        recheck_borderline(ritzv, resd, sub);
         if (resd != resid_.data() + locked_) std::memcpy(resid_.data() + locked_, resd, sub * sizeof(R));
     }
+
+    // Lock on what the reference would see (see ChaseHip::recheck_borderline): residuals within 1e-3 of the tolerance are
+    // taken again from the reference's residual step as it stands (mpi/residuals.hpp:61-107: fresh four-product H v,
+    // column -> row redistribution of v, local sums of squares, all-reduce over the row group) on just those columns.
+    // Collective: the residuals were agreed above, so every rank selects the same columns.
+    void recheck_borderline(const R* ritzv, R* resd, std::size_t sub)
+    {
+        static const bool on = [] { const char* e = std::getenv("CHASE_HIP_RESD_RECHECK"); return e ? std::atoi(e) != 0 : true; }();
+        if (!on) return;
+        const R tol = (R)config_.GetTol();
+        std::vector<std::size_t> idx;
+        for (std::size_t j = 0; j < sub; ++j)
+            if (std::abs(resd[j] - tol) <= (R)1e-3 * tol) idx.push_back(j);
+        const std::size_t k = idx.size();
+        if (k == 0 || k > 256 || k > nc_) return;
+        if (chk_cols_ < 2 * k) {                                           // row-type scratch: H v and v of the k columns
+            const std::size_t cols = (2 * k + 31) / 32 * 32;
+            alloc((void**)&dChk_, n_ * cols * sizeof(T));                 // (grow-only; an outgrown block lives until the Impl dies)
+            chk_cols_ = cols;
+        }
+        std::vector<R> lam(k), sq(k);
+        for (std::size_t i = 0; i < k; ++i) {
+            lam[i] = ritzv[idx[i]];
+            hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, 1, dV1_ + (locked_ + idx[i]) * m_, (long)m_, dVt_ + i * m_, (long)m_), "lacpy");
+        }
+        T* HVr = dChk_;
+        T* Vr = dChk_ + k * n_;
+        chase_hip_ctx_set_phase(ctx_, 3);
+        hemm_ptr(true, dVt_, HVr, 0, k, T(1), T(0), false);
+        chase_hip_ctx_set_phase(ctx_, 0);
+        redistribute_c2r(dVt_, Vr, k);
+        hip_ok(chase_hip_resid_norms(ctx_, CP, (int)n_, (int)k, HVr, (long)n_, Vr, (long)n_, lam.data(), sq.data(), 1), "resid_norms");
+        double* d = (double*)dPack_;
+        hip_ok(chase_hip_memcpy_h2d(ctx_, d, sq.data(), k * sizeof(double)), "h2d");
+        coll(chase_hip_grid_allreduce(grid_, CHASE_HIP_ROW, d, k, 0));
+        hip_ok(chase_hip_memcpy_d2h(ctx_, sq.data(), d, k * sizeof(double)), "d2h");
+        for (std::size_t i = 0; i < k; ++i) sq[i] = std::sqrt(sq[i]);
+        agree_vector(sq.data(), k, nullptr, 0);
+        for (std::size_t i = 0; i < k; ++i) resd[idx[i]] = sq[i];
+        resd_rechecked_ += k;
+    }
+    std::size_t resd_rechecked() const override { return resd_rechecked_; }
 
     // the reference's residual step as it stands (mpi/residuals.hpp:61-107: H V, column -> row redistribution of V, local
     // sums of squares, all-reduce over the row group) on the first ncols vectors, never from cached products
@@ -379,7 +423,7 @@ public:
         flush_swaps(); sync_comm();
         hv_valid_ = false;                                                   // dW1_ / dW2_ are scratch from here on
         hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)ncols, dV1_, (long)m_, dV2_, (long)m_), "lacpy");
-        chase_hip_ctx_set_phase(ctx_, 2);
+        chase_hip_ctx_set_phase(ctx_, 3);                                    // four real products per complex product, always
         hemm_ptr(true, dV1_, dW1_, 0, ncols, T(1), T(0), false);             // W1 = H^H V1 (row-type), all-reduced
         chase_hip_ctx_set_phase(ctx_, 0);
         redistribute_c2r(dV2_, dW2_, ncols);
@@ -761,6 +805,7 @@ protected:
     std::size_t hv_locked_ = 0, hv_block_ = 0, hemm_reused_vecs_ = 0;
     double hv_shift_ = 0.0;
     T* dW3_ = nullptr;
+    T* dChk_ = nullptr; std::size_t chk_cols_ = 0, resd_rechecked_ = 0;   // scratch of recheck_borderline
     T *dV1_ = nullptr, *dV2_ = nullptr, *dVt_ = nullptr, *dW1_ = nullptr, *dW2_ = nullptr, *dA_ = nullptr;
     T *dPack_ = nullptr, *dStage_ = nullptr;
     std::size_t pack_elems_ = 0;

@@ -228,6 +228,7 @@ int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* out)
         else if (name == "filter_ms") *out = s->ex->filter_ms();
         else if (name == "hemm_calls") *out = (double)s->ex->hemm_calls();
         else if (name == "hemm_reused_vecs") *out = (double)s->ex->hemm_reused_vecs();
+        else if (name == "resd_rechecked") *out = (double)s->ex->resd_rechecked();
         else if (name == "iterations") *out = (double)s->stats.iterations;          // of the last solve
         else if (name == "filtered_vecs") *out = (double)s->stats.filtered_vecs;
         else rc = chase_hip::set_error(CHASE_HIP_EINVAL, "solver_get: unknown key");

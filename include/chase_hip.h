@@ -70,14 +70,15 @@ int chase_hip_gemm_d(chase_hip_ctx* ctx, char opA, int m, int n, int k, double a
 int chase_hip_gemm_z(chase_hip_ctx* ctx, char opA, int m, int n, int k, const double alpha[2], const void* A,
                      long lda, const void* B, long ldb, const double beta[2], void* C, long ldc);
 
-/* 1 when complex products issued in phase 1 (chase_hip_ctx_set_phase: the Chebyshev filter) use the three-multiplication
- * scheme (default; CHASE_HIP_GEMM3M=0 or chase_hip_set_gemm3m(0) selects the four-multiplication kernel, the arithmetic
- * of the reference's zgemm).  It applies to launches with m a multiple of 128, k a multiple of 8 and 16-byte addressable
- * operands; other shapes, and every product outside the filter (Rayleigh-Ritz, residuals, Gram matrices), take the
+/* 1 when complex products issued in phase 1 (chase_hip_ctx_set_phase: the Chebyshev filter) and phase 2 (the H-times-block
+ * products of Rayleigh-Ritz / residuals; CHASE_HIP_GEMM3M_RR=0 keeps those on four) use the three-multiplication scheme
+ * (default; CHASE_HIP_GEMM3M=0 or chase_hip_set_gemm3m(0) selects the four-multiplication kernel, the arithmetic of the
+ * reference's zgemm).  It applies to launches with m a multiple of 128, k a multiple of 8 and 16-byte addressable
+ * operands; other shapes, and every other product (Gram matrices, back-transforms, QR, phase 3), take the
  * four-multiplication kernel. */
 int chase_hip_gemm3m_enabled(void);
 int chase_hip_set_gemm3m(int on); /* process-wide run-time switch */
-/* GEMM books of a context, per phase (0 other, 1 filter, 2 H-times-block outside the filter): flops in the reference's
+/* GEMM books of a context, per phase (0 other, 1 filter, 2 H-times-block outside the filter, 3 verification): flops in the reference's
  * model (2*F*m*n*k, F = 4 complex: algorithm/performance.hpp:152,250), flops the matrix cores actually executed (3/4 of
  * the model for three-multiplication launches) and the number of products.  Any output pointer may be NULL. */
 int chase_hip_ctx_gemm_counters(chase_hip_ctx* ctx, int phase, double* flops_model, double* flops_executed,
@@ -89,9 +90,9 @@ int chase_hip_hbm_copy_peak(chase_hip_ctx* ctx, size_t bytes, double* gbps);
 
 /* phase 1 = inside FilterPhaseStart/End: GEMMs are launched through the filter-tagged kernel symbol so that rocprofv3
  * reports the Chebyshev-filter HEMM separately; phase 2 = an H-times-block product outside the filter (Rayleigh-Ritz,
- * residuals): ordinary symbol, four multiplications (CHASE_HIP_GEMM3M_RR=1 opts them into the three-multiplication
- * scheme).  Complex products of phase 1 may use the three-multiplication scheme (see chase_hip_gemm3m_enabled);
- * 0 = everything else (always four multiplications) */
+ * residuals): ordinary symbol, three multiplications like the filter (CHASE_HIP_GEMM3M_RR=0: four); phase 3 = a
+ * verification product (independent residuals, the re-check of residuals that sit on the tolerance): always four
+ * multiplications, the arithmetic of the reference's zgemm; 0 = everything else (always four multiplications) */
 int chase_hip_ctx_set_phase(chase_hip_ctx* ctx, int phase);
 /* Granularity of the following products: rounds > 0 says they share the chip with a collective on another stream (the panel
  * products of the pipelined distributed HEMM) - a product with fewer than `rounds` output tiles per workgroup slot is then cut
@@ -177,6 +178,11 @@ int chase_hip_resid_norms(chase_hip_ctx* ctx, int cplx, int m, int n, const void
 
 /* ---- Cholesky-QR building blocks (replace cublasTsyherk / cusolverDnTpotrf / cublasTtrsm, cuda/cholqr.hpp:110-132) */
 int chase_hip_herk(chase_hip_ctx* ctx, int cplx, int n, int k, const void* V, long ldv, void* A, long lda);
+/* C (n x n) = A^H B for k x n operands whose product is Hermitian (Gram matrix: A = B; projected matrix of Rayleigh-Ritz:
+ * A = H Q, B = Q; linalg/internal/cuda/cholqr.hpp:110-112 cublasTsyherk, nccl/rayleighRitz.hpp:118-129): only the block
+ * columns' parts on and above the diagonal are multiplied; mirror != 0 also fills the strictly lower triangle */
+int chase_hip_herkx(chase_hip_ctx* ctx, int cplx, int n, int k, const void* A, long lda, const void* B, long ldb, void* C,
+                    long ldc, int mirror);
 int chase_hip_abs_trace(chase_hip_ctx* ctx, int cplx, int n, const void* A, long lda, double* out_host);
 /* returns 0 or LAPACK info > 0 (first non-positive pivot) */
 int chase_hip_potrf_upper(chase_hip_ctx* ctx, int cplx, int n, void* A, long lda);

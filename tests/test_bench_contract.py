@@ -108,8 +108,64 @@ def test_spawned_ranks_carry_the_binding(monkeypatch):
 
     class A:
         gpus = 4
-    rc = B.spawn_ranks(A, ["--gpus", "4"])
+    rc = B.spawn_ranks(A, ["--gpus", "4"], "bound")
     assert rc == 1                                           # no result line from fake ranks
     assert [e["ROCR_VISIBLE_DEVICES"] for e in seen] == ["0", "1", "2", "3"]
     assert [e["LOCAL_RANK"] for e in seen] == ["0", "1", "2", "3"] and all(e["WORLD_SIZE"] == "4" for e in seen)
     assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in seen)
+    assert all(e["CHASE_BENCH_MODE"] == "bound" for e in seen)              # the ranks do not probe again
+    # all devices visible, device = local rank (the reference's way, grid/mpiGrid2D.hpp:225-233)
+    del seen[:]
+    B.spawn_ranks(A, ["--gpus", "4"], "unbound")
+    assert all("ROCR_VISIBLE_DEVICES" not in e and e["CHASE_HIP_BIND"] == "0" for e in seen)
+
+
+def test_mode_selection_tries_bound_then_unbound_then_threads(monkeypatch):
+    """`--ranks auto`: the way the ranks hold their devices is decided by probe children (context + RCCL communicators + the
+    256 MB all-reduce proof) before the deciding process touches a GPU; the probes are answered by a test hook here.  As the
+    parent of its own ranks and as one rank of a torch.distributed.run launch the decision is the same."""
+    class A:
+        gpus = 4
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(key, raising=False)
+    for spec, want in (({"bound": 0, "unbound": 0}, "bound"), ({"bound": 5, "unbound": 0}, "unbound"),
+                       ({"bound": 124, "unbound": 4}, "threads")):
+        monkeypatch.setenv("CHASE_BENCH_FAKE_PROBE", json.dumps(spec))
+        assert B.choose_mode_as_parent(A, ["--gpus", "4"]) == want
+        monkeypatch.setenv("RANK", "2"); monkeypatch.setenv("WORLD_SIZE", "4"); monkeypatch.setenv("LOCAL_RANK", "2")
+        assert B.choose_mode_as_rank(A, ["--gpus", "4"]) == want
+        for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            monkeypatch.delenv(key, raising=False)
+
+
+def test_thread_mode_under_a_launcher_leaves_the_gpu_to_rank_zero(tmp_path):
+    """`--ranks threads` under torch.distributed.run: rank 0 hosts one thread per GPU, every other rank leaves with status 0
+    before it imports anything that touches a GPU (no output, no device context)."""
+    env = dict(os.environ, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--ranks", "threads", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 0 and p.stdout.strip() == "" and "device" not in p.stderr
+
+
+def test_cpu_baseline_runs_as_a_child_and_is_joined_before_the_timed_region():
+    job = B.CpuBaselineJob(384, True, 32, 0.5)
+    s = FakeSolver()
+    order = []
+    timer = B.StepTimer(2, 1, lambda: order.append("sync"), lambda: None, lambda: dict(s.counters),
+                        before_timed=lambda: (order.append("join"), job.join()))
+    B.run_timed_solves(s, timer, s.nev, lambda: ("lam", "res"))
+    assert order[:2] == ["join", "sync"]                     # the child is over before the opening bracket
+    rec = job.result()
+    assert rec["value"] > 0 and rec["kind"] == "port" and "child process" in rec["ran"]
+    assert rec["sample_shape"]["N"] == 384
+
+
+def test_converged_flag_holds_the_solvers_own_tolerance_on_recomputed_residuals():
+    import numpy as np
+    lam = np.arange(4.0)
+    tol = 1e-10
+    ok = {"ok": True}
+    assert B.converged_ok(lam, [5e-11, 9.9e-11, 3e-10, 1e-11], [5e-11, 1.0005e-10, 3e-10, 1e-11], tol, ok)   # early-locked pair above tol is fine
+    assert not B.converged_ok(lam, [5e-11, 9.9e-11, 3e-10, 1e-11], [5e-11, 1.01e-10, 3e-10, 1e-11], tol, ok)  # converged by the solver, not by H
+    assert not B.converged_ok(lam, [5e-11] * 4, [5e-11] * 4, tol, {"ok": False})
+    assert not B.converged_ok([0, 1, np.nan, 3], [5e-11] * 4, [5e-11] * 4, tol, ok)

@@ -57,6 +57,20 @@ def test_multi_rank_entry_point_on_one_gpu():
     assert d["iterations_per_solve"] == 9
     p = d["comm_probe"]
     assert p["col_group_panel_allreduce"]["ranks"] == 2 and p["panel_gemm_alone_ms_rounds4"] > 0
+    # every multi-rank run times a 256 MB all-reduce per communicator before it solves (a host-staged RCCL group fails it)
+    t = d["transport_proof"]
+    assert t["ok"] and t["row_group"]["ranks"] == 2 and t["col_group"]["busbw_GBps"] > 0
+
+
+def test_thread_per_gpu_mode_on_one_gpu():
+    """`bench.py --gpus 4 --ranks threads`: ONE process, one thread per rank - here four threads on this box's one
+    device over the host test transport; on the multi-GPU node the same code opens device r in thread r and creates the RCCL
+    communicators from the four threads."""
+    d = run_bench("--gpus", "4", "--ranks", "threads", "--workload", "cfg2", "--steps", "9", "--warmup", "0", "--no-cpu-baseline",
+                  "--no-probe", env={"CHASE_HIP_TRANSPORT": "host"})
+    check_common(d, 4, 9, 0)
+    assert d["config"]["grid"] == "2x2" and d["config"]["ranks"] == "threads of one process"
+    assert d["iterations_per_solve"] == 9 and d["transport_proof"]["ok"]
 
 
 def test_rank_of_a_torchrun_launch_on_one_gpu():

@@ -426,7 +426,8 @@ def test_three_vs_four_multiplication_accuracy(ctx, imag_scale):
     four-multiplication kernel (the reference's zgemm arithmetic), on generic AND on nearly real operands (the bench matrix
     is nearly real): 3M must meet the NORMWISE bound |C - AB| <= c k eps |A||B| (entrywise in terms of the moduli), 4M the
     componentwise-in-real-arithmetic bound on the real and on the imaginary part separately.  Also checks the switch: the
-    3M launch executes 3/4 of the model flops, the 4M launch all of them, and 3M is used in phase 1 only."""
+    3M launch executes 3/4 of the model flops, the 4M launch all of them; phase 1 (filter) and - since round 4 - phase 2
+    (H-times-block of Rayleigh-Ritz / residuals) take 3M, phase 3 (verification products) and phase 0 never do."""
     from chase_amd.capi import lib, gemm_counters
     rng = np.random.default_rng(3)
     m, k, n = 256, 4096, 64
@@ -439,7 +440,7 @@ def test_three_vs_four_multiplication_accuracy(ctx, imag_scale):
     im_scale = np.abs(A.real) @ np.abs(B.imag) + np.abs(A.imag) @ np.abs(B.real)
     dA, dB = ctx.array(A), ctx.array(B)
     res = {}
-    for name, phase, on in (("4M", 1, 0), ("3M", 1, 1), ("phase2", 2, 1)):
+    for name, phase, on in (("4M", 1, 0), ("3M", 1, 1), ("phase2", 2, 1), ("phase3", 3, 1), ("phase0", 0, 1)):
         lib.chase_hip_set_gemm3m(on)
         lib.chase_hip_ctx_set_phase(ctx.h, phase)
         try:
@@ -455,14 +456,17 @@ def test_three_vs_four_multiplication_accuracy(ctx, imag_scale):
         ei = np.abs(C.imag.astype(np.longdouble) - Ri).astype(np.float64)
         res[name] = (er, ei, (e1 - e0) / (m1 - m0))
         assert m1 - m0 == 2.0 * 4 * m * n * k
-    # executed share of the model flops: exactly 3/4 for the 3M launch, 1 for 4M and for every product outside the filter
-    assert res["3M"][2] == 0.75 and res["4M"][2] == 1.0 and res["phase2"][2] == 1.0
+    # executed share of the model flops: exactly 3/4 for the 3M launches, 1 for 4M, verification and ordinary products
+    assert res["3M"][2] == 0.75 and res["4M"][2] == 1.0 and res["phase2"][2] == 0.75
+    assert res["phase3"][2] == 1.0 and res["phase0"][2] == 1.0
+    for name in ("4M", "phase3", "phase0"):
+        er4, ei4, _ = res[name]
+        assert np.max(er4 / re_scale) < 4 * GEMM_TOL and np.max(ei4 / im_scale) < 4 * GEMM_TOL  # componentwise (4M)
     er4, ei4, _ = res["4M"]
-    assert np.max(er4 / re_scale) < 4 * GEMM_TOL and np.max(ei4 / im_scale) < 4 * GEMM_TOL      # componentwise (4M)
-    er2, ei2, _ = res["phase2"]
-    assert np.max(er2 / re_scale) < 4 * GEMM_TOL and np.max(ei2 / im_scale) < 4 * GEMM_TOL      # RR / residual products
+    for name in ("3M", "phase2"):
+        er3, ei3, _ = res[name]
+        assert np.max(np.hypot(er3, ei3) / mod) < 8 * GEMM_TOL                                  # normwise (3M)
     er3, ei3, _ = res["3M"]
-    assert np.max(np.hypot(er3, ei3) / mod) < 8 * GEMM_TOL                                      # normwise (3M)
     if imag_scale < 1e-4:
         # documents WHY 3M stays inside the filter: the tiny imaginary part inherits the real part's absolute error
         assert np.max(ei3 / im_scale) > 100 * np.max(ei4 / im_scale)
@@ -622,3 +626,50 @@ def test_tridiagonal_divide_and_conquer_on_the_device(ctx, n):
         assert np.max(np.abs(T @ Z - Z * w[None, :])) <= 10 * nn * EPS * nrm, (name, np.max(np.abs(T @ Z - Z * w[None, :])) / (nn * EPS * nrm))
         assert np.max(np.abs(Z.T @ Z - np.eye(nn))) <= 10 * nn * EPS, (name, np.max(np.abs(Z.T @ Z - np.eye(nn))) / (nn * EPS))
         assert np.max(np.abs(w - np.linalg.eigvalsh(T))) <= 10 * nn * EPS * nrm, name
+
+
+@pytest.mark.parametrize("cplx,n,k", [(True, 1280, 4096), (False, 1536, 2048), (True, 300, 1000), (False, 1100, 777)])
+def test_herkx_upper_block_trapezoid_matches_numpy(ctx, cplx, n, k):
+    """chase_hip_herkx: C = A^H B for a Hermitian product from the block columns' parts on and above the diagonal only
+    (cublasTsyherk in the reference, cuda/cholqr.hpp:110-112): upper triangle equal to the full product, lower triangle the
+    mirror (or untouched), and fewer model flops on the books than the full product for n >= 4 blocks."""
+    from chase_amd.capi import lib, check, gemm_counters
+    rng = np.random.default_rng(5)
+    dt = np.complex128 if cplx else np.float64
+    Q = rng.standard_normal((k, n)) + (1j * rng.standard_normal((k, n)) if cplx else 0)
+    Q = np.asfortranarray(Q.astype(dt))
+    S = rng.standard_normal((k, k)) + (1j * rng.standard_normal((k, k)) if cplx else 0)
+    W = np.asfortranarray(((S + S.conj().T) @ Q).astype(dt))                  # W^H Q = Q^H (S + S^H) Q is Hermitian
+    ref = W.conj().T @ Q
+    scale = np.abs(W).T @ np.abs(Q)
+    dW, dQ = ctx.array(W), ctx.array(Q)
+    for mirror in (1, 0):
+        C0 = np.full((n, n), 7.0, dtype=dt, order="F")
+        dC = ctx.array(C0)
+        m0, _, _ = gemm_counters(ctx, 0)
+        check(lib.chase_hip_herkx(ctx.h, int(cplx), n, k, dW.ptr, k, dQ.ptr, k, dC.ptr, n, mirror), "herkx")
+        m1, _, _ = gemm_counters(ctx, 0)
+        C = dC.download()
+        iu = np.triu_indices(n)
+        assert np.max(np.abs(C[iu] - ref[iu]) / scale[iu]) < 8 * GEMM_TOL
+        il = np.tril_indices(n, -1)
+        if mirror:
+            assert np.array_equal(C[il], np.conj(C.T)[il])
+        elif n >= 1024:
+            # untouched below the block trapezoid (inside a diagonal block the whole block is written)
+            blk = il[0] // 256 > il[1] // 256
+            assert np.all(C[il][blk] == 7.0)
+        full = 2.0 * (4 if cplx else 1) * n * n * k
+        if n >= 1024:
+            assert (m1 - m0) < 0.7 * full, ((m1 - m0) / full)
+        else:
+            assert (m1 - m0) == full
+        dC.free()
+    # the Gram form: herk == herkx(V, V)
+    dA = ctx.array(np.zeros((n, n), dtype=dt, order="F"))
+    check(lib.chase_hip_herk(ctx.h, int(cplx), n, k, dQ.ptr, k, dA.ptr, n), "herk")
+    G = dA.download()
+    gref = Q.conj().T @ Q
+    assert np.max(np.abs(G - gref) / (np.abs(Q).T @ np.abs(Q))) < 8 * GEMM_TOL
+    for d in (dW, dQ, dA):
+        d.free()

@@ -602,3 +602,53 @@ def test_c_interface_misuse_and_bad_input_are_harmless(ctx):
     solve("dchase_")                                                        # returns; the failure is on record
     assert lib.chase_hip_last_error() != b""
     lib.dchase_finalize_(C.byref(flag))
+
+
+def test_rayleigh_ritz_on_three_products_and_residuals_on_the_tolerance(ctx):
+    """Round 4: the H-times-block product of Rayleigh-Ritz runs on three real products per complex product like the filter.
+    (a) Ritz values agree with the four-product run to 1e-12 ||H|| (the verdict's bar); (b) the residuals agree to
+    ~1e-13 ||H||; (c) a residual that sits within 1e-3 of the tolerance is taken again from a fresh FOUR-product H v of that
+    column before the driver sees it (ChaseHip::recheck_borderline), and equals the independent recompute_residuals value."""
+    from chase_amd.capi import Solver, lib, gemm_counters
+    N, nev, nex = 1024, 60, 36
+    n = nev + nex
+    H = _random_phase_clement(N)
+    normH = float(N)
+
+    def leg(on):
+        lib.chase_hip_set_gemm3m(on)
+        try:
+            s = Solver(ctx, H, nev, nex)
+            s.Start(); s.initVecs(True); s.QR(0, 1.0)
+            c = 40.0
+            s.Shift(-c)
+            for (a, b) in [(0.002, 0.0), (0.004, -0.3), (0.004, -0.25), (0.004, -0.25)]:
+                s.HEMM(n, a, b, 0)
+            s.Shift(c, True)
+            s.QR(0, 1e3)
+            m0, e0, _ = gemm_counters(ctx, 2)
+            s.RR(n, 0)
+            m1, e1, _ = gemm_counters(ctx, 2)
+            r = s.Resd(0)
+            return s, s.ritzv[:n].copy(), r, (e1 - e0) / (m1 - m0)
+        finally:
+            lib.chase_hip_set_gemm3m(1)
+
+    s3, lam3, r3, x3 = leg(1)
+    s4, lam4, r4, x4 = leg(0)
+    assert x3 == 0.75 and x4 == 1.0
+    assert np.max(np.abs(lam3 - lam4)) <= 1e-12 * normH                      # (a)
+    assert np.max(np.abs(r3 - r4)) <= 1e-12 * normH                          # (b)
+    s4.close()
+    # (c) put the tolerance ON residual j and ask again: RR's products are still valid, so only the re-check runs
+    j = 7
+    before = s3.get("resd_rechecked")
+    s3.set(tol=float(r3[j]))
+    r3c = s3.Resd(0)
+    assert s3.get("resd_rechecked") - before >= 1
+    near = set(np.nonzero(np.abs(r3 - r3[j]) <= 1e-3 * r3[j])[0].tolist())
+    assert j in near and set(np.nonzero(r3c != r3)[0].tolist()) <= near       # only residuals on the tolerance were re-taken
+    fresh = s3.recompute_residuals(n, lam3)                                   # independent: fresh four-product H V of all columns
+    assert abs(r3c[j] - fresh[j]) <= 1e-13 * normH
+    assert np.max(np.abs(r3c - fresh)) <= 1e-12 * normH
+    s3.close()
