@@ -617,7 +617,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                     cluster(stn, 0, yes, fill_c, st);                          // chunk 1 of tile kt (+ the copies of tile kt+STAGES)
                 };
                 int kt = 0;
-                if constexpr (C_::STAGES == 3) {
+                // (not for the ragged op = C instantiation: the loop-invariant address registers of the unrolled form are what
+                // pushed it one register over 256 - a spill in the K loop; its launches are 1 % of a solve's filter time)
+                if constexpr (C_::STAGES == 3 && !(RAGGED && OPA_C)) {
                     // steady state, three K steps per trip: the stage indices are compile-time constants, so every LDS
                     // address is a loop-invariant register plus an immediate offset (no address arithmetic in the loop)
                     for (; kt + 2 + C_::STAGES < nfull; kt += 3) {

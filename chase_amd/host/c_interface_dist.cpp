@@ -95,14 +95,14 @@ struct SlotTable {
     }
     void finalize()
     {
-        std::unique_ptr<DistSlot> mine;
+        DistSlot* mine = nullptr;
         {
             std::lock_guard<std::mutex> lk(mu);
             auto it = extra.find(std::this_thread::get_id());
-            if (it != extra.end()) { mine = std::move(it->second); extra.erase(it); }
+            if (it != extra.end()) mine = it->second.get();        // stays this thread's (now empty) slot: what it sees from now on
             else claimed = false;
         }
-        if (mine) mine->clear(); else global.clear();
+        (mine ? *mine : global).clear();
     }
 };
 SlotTable g_td, g_tz;

@@ -143,3 +143,42 @@ def test_grid_solver_takes_the_reference_distributed_path_count_for_count(nprow,
 def test_pseudo_grid_solver_takes_the_reference_distributed_path_count_for_count(nprow, npcol, mb):
     from rank_threads import run_ranks as run_grid
     run_grid(nprow, npcol, S.scenario_pseudo_solve_counts, mb)
+
+
+def test_c_interface_slot_is_process_wide_like_the_reference(ctx):
+    """The reference keeps one static distributed solver per type for the PROCESS (chase_c_interface.cpp:905-1290): an
+    application may call p?chase_init_ on one thread and p?chase_ / get_eigenpairs / finalize on another.  (Only when a second
+    thread initialises a solver of the same type while the first is alive - rank threads of one process - does it get its
+    own slot: every other test of this file.)"""
+    import ctypes as C
+    import threading
+    import numpy as np
+    from chase_amd.capi import lib
+    from chase_amd import dist as cd
+    from oracle import chase_oracle as O
+    N, nev, nex = 200, 16, 12
+    H = np.asfortranarray(O.clement(N, False))
+    V = np.zeros((N, nev + nex), order="F")
+    ritzv = np.zeros(nev + nex)
+    grid = cd.Grid(ctx, 1, 1, 0, transport="host", pg=None)
+    I = lambda v: C.byref(C.c_int(v))
+    init = C.c_int(0)
+
+    def on_worker():
+        lib.chase_hip_cshim_use_ctx(C.c_void_p(ctx.h.value), 0)
+        lib.pdchase_init_hip_(I(N), I(nev), I(nex), I(N), I(N), C.c_void_p(H.ctypes.data), I(N), C.c_void_p(V.ctypes.data),
+                              C.c_void_p(ritzv.ctypes.data), C.c_void_p(grid.h.value), C.byref(init))
+
+    t = threading.Thread(target=on_worker)
+    t.start(); t.join()
+    assert init.value == 1, lib.chase_hip_last_error()
+    lib.chase_hip_cshim_dist_solver.restype = C.c_void_p
+    assert lib.chase_hip_cshim_dist_solver(0)                       # visible from THIS thread
+    deg, tol = C.c_int(20), C.c_double(1e-10)
+    lib.pdchase_(C.byref(deg), C.byref(tol), C.c_char_p(b"R"), C.c_char_p(b"S"), C.c_char_p(b"C"))
+    assert np.max(np.abs(ritzv[:nev] - (-N + 2.0 * np.arange(nev)))) < 1e-4      # Clement spectrum (1e-6 perturbation)
+    assert np.max(O.residuals(H, ritzv[:nev], V[:, :nev])) < 1e-8
+    flag = C.c_int(3)
+    lib.pdchase_finalize_(C.byref(flag))
+    assert flag.value == 0 and not lib.chase_hip_cshim_dist_solver(0)
+    grid.close()

@@ -235,3 +235,38 @@ def test_real_pseudo_hermitian_fixture_solve(ctx):
     assert np.max(np.abs(np.sort(ko.ritzv[:nev]) - pos[:nev])) <= 1e-9
     assert abs(st["iterations"] - so["iterations"]) <= 2
     s.close()
+
+
+@pytest.mark.parametrize("cplx,n", [(True, 640), (False, 400), (True, 96)])
+def test_pseudo_rayleigh_ritz_dense_core(ctx, cplx, n):
+    """chase_hip_pseudo_rr_small: the dense core of rayleighRitz_v2 (cpu/rayleighRitz.hpp:316-383: potrf, L^{-1} M L^{-H}, heevd,
+    back-substitution, 1 / -w, normalisation).  For cores of 384 and more every step runs on the device (potrf_upper, one
+    right-solve for R^{-1}, MFMA GEMMs, heevd_gpu - the reference's GPU path cuda/rayleighRitz.hpp:511-600), below that on the
+    host LAPACK: both against scipy's generalised eigensolver.  n = 640 is config 5's core (2 (nev + nex))."""
+    import scipy.linalg as sla
+    from chase_amd.capi import lib, check
+    rng = np.random.default_rng(17)
+    def herm(scale):
+        X = rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if cplx else 0)
+        return scale * (X + X.conj().T) / 2
+    A = herm(0.05) + np.diag(np.linspace(1.0, 9.0, n))                     # Q^H S H Q: Hermitian positive definite
+    M = herm(0.05) + np.diag(np.where(np.arange(n) % 2 == 0, 1.0, -1.0))  # Q^H S Q: Hermitian indefinite
+    A = np.asfortranarray(A.astype(np.complex128 if cplx else np.float64))
+    M = np.asfortranarray(M.astype(A.dtype))
+    dA, dM = ctx.array(A), ctx.array(M)
+    ritz = np.zeros(n)
+    check(lib.chase_hip_pseudo_rr_small(ctx.h, int(cplx), n, dA.ptr, dM.ptr, ritz.ctypes.data), "pseudo_rr_small")
+    X = dM.download()
+    mu = sla.eigh(M, A, eigvals_only=True)                                # M x = mu A x, ascending
+    want = 1.0 / mu[::-1]                                                  # w = -mu ascending  ->  ritz = 1 / -w
+    assert np.max(np.abs(ritz - want) / np.abs(want)) < 1e-10
+    h = n // 2
+    assert np.max(np.abs(np.linalg.norm(X[:, :h], axis=0) - 1)) < 1e-12   # first n/2 vectors normalised
+    R = A @ X[:, :h] - (M @ X[:, :h]) * ritz[:h]                           # A x = ritz M x
+    assert np.max(np.linalg.norm(R, axis=0)) < 1e-10 * np.linalg.norm(A, 2) * np.max(np.abs(ritz[:h]))
+    # not positive definite -> the potrf info comes back as a positive status
+    A[5, 5] = -1.0
+    dA.upload(A); dM.upload(M)
+    rc = lib.chase_hip_pseudo_rr_small(ctx.h, int(cplx), n, dA.ptr, dM.ptr, ritz.ctypes.data)
+    assert 0 < rc <= n
+    dA.free(); dM.free()
