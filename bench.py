@@ -630,6 +630,10 @@ def choose_mode_as_rank(args, argv):
         if rc is None:
             env = mode_env(os.environ, mode, local_rank)
             env["MASTER_PORT"] = str(base + 101 + i if base + 101 + i < 65536 else base - 101 - i)
+            # the children rendezvous among themselves: rank 0's child hosts the store on that port (the launcher's agent store
+            # on MASTER_PORT belongs to the rank processes)
+            for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+                env.pop(k)
             env["CHASE_BENCH_QUIET"] = "1"
             rc = run_children([([sys.executable, os.path.abspath(__file__)] + argv + ["--transport-probe"], env, None)],
                               PROBE_TIMEOUT_S)

@@ -290,8 +290,7 @@ int chase_hip_herkx(chase_hip_ctx* c, int cplx, int n, int k, const void* A_, lo
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "herkx: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
-    const long kmin = k > 1 ? k : 1;
-    if (n < 0 || k < 0 || lda < kmin || ldb < kmin || ldc < n) return set_error(CHASE_HIP_EINVAL, "herkx: bad shape");
+    if (n < 0 || k < 0 || lda < k || ldb < k || ldc < n) return set_error(CHASE_HIP_EINVAL, "herkx: bad shape");   // k = 0: C = 0
     if (n == 0) return 0;
     const int e = ept_of(cplx);
     const double *A = (const double*)A_, *B = (const double*)B_;

@@ -201,7 +201,9 @@ static int check_gemm(char opA, int m, int n, int k, const void* A, long lda, co
     if (m == 0 || n == 0) return 0;
     if (!C || (k > 0 && (!A || !B))) return set_error(CHASE_HIP_EINVAL, "gemm: NULL matrix pointer");
     const long arows = opn ? m : k;
-    if (lda < (arows > 1 ? arows : 1) || ldb < (k > 1 ? k : 1) || ldc < m)
+    // (an operand without rows - k = 0: a rank that owns no rows of the block - may come with leading dimension 0; the
+    // product is then beta C and nothing of A or B is read)
+    if (lda < arows || ldb < k || ldc < m || (k > 0 && (lda < 1 || ldb < 1)))
         return set_error(CHASE_HIP_EINVAL, "gemm: leading dimension too small");
     return 0;
 }

@@ -73,7 +73,9 @@ public:
         Cc_.nloc = Cc_.count(mycol_);
         m_ = (std::size_t)Rr_.nloc; n_ = (std::size_t)Cc_.nloc;
         if (ldh < m_) throw std::invalid_argument("pChaseHip: ldh smaller than the local row count");
-        if (m_ == 0 || n_ == 0) throw std::invalid_argument("pChaseHip: empty local block (grid too large for N)");
+        // a rank may own NO rows or columns: the reference's block rule (distMatrix.hpp:1992-2052) gives the last rank of a
+        // dimension N - (p - 1) len of them, which is 0 for N = 9 on 4 grid rows (3, 3, 3, 0) - such a rank takes part in
+        // every collective with empty blocks (all products, copies and reductions below accept zero rows)
         for (std::size_t i = 0; i < nc_; ++i) perm_[i] = (int)i;
         alloc((void**)&dV1_, m_ * nc_ * sizeof(T));
         alloc((void**)&dV2_, m_ * nc_ * sizeof(T));
@@ -93,7 +95,7 @@ public:
         // fixed for the object's life time (the per-panel events are indexed by it)
         {
             const std::size_t bn = CP ? 64 : 128, slots = 512;
-            auto need = [&](std::size_t rows) { const std::size_t rt = (rows + 127) / 128; return ((slots + rt - 1) / rt) * bn; };
+            auto need = [&](std::size_t rows) { const std::size_t rt = std::max<std::size_t>(1, (rows + 127) / 128); return ((slots + rt - 1) / rt) * bn; };
             const std::size_t w = std::max(need(m_), need(n_));
             panel_ = std::min<std::size_t>(2048, std::max<std::size_t>(256, (w + 255) / 256 * 256));
         }

@@ -169,3 +169,24 @@ def test_converged_flag_holds_the_solvers_own_tolerance_on_recomputed_residuals(
     assert not B.converged_ok(lam, [5e-11, 9.9e-11, 3e-10, 1e-11], [5e-11, 1.01e-10, 3e-10, 1e-11], tol, ok)  # converged by the solver, not by H
     assert not B.converged_ok(lam, [5e-11] * 4, [5e-11] * 4, tol, {"ok": False})
     assert not B.converged_ok([0, 1, np.nan, 3], [5e-11] * 4, [5e-11] * 4, tol, ok)
+
+
+def test_mode_selection_under_the_real_launcher_without_a_gpu():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` (the driver's multi-GPU call) on a box without a
+    GPU: every rank settles the mode through its own probe children - which must find each other on their own port although
+    the launcher's agent store owns MASTER_PORT -, both process modes fail for lack of a device, the thread mode is refused for
+    the same reason, and the job ends non-zero without a result line."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                           "CHASE_HIP_TRANSPORT", "CHASE_BENCH_FAKE_PROBE")}
+    env["CHASE_BENCH_PROBE_TIMEOUT"] = "120"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0
+    assert "probe of mode 'bound': exit status 3" in p.stderr and "probe of mode 'unbound': exit status 3" in p.stderr
+    assert "no usable device context" in p.stderr                          # the probes met and agreed (status 3, not a timeout)
+    assert "--ranks threads needs one GPU per rank" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

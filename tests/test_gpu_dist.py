@@ -113,6 +113,9 @@ def test_grid_sendrecv_and_exact_agree_max(nranks):
     (2, 2, 130, 12, 1, True, 1),          # one extra vector, block-cyclic with 1 x 1 blocks
     (4, 1, 257, 30, 20, False, 64),       # last grid rows own a single partial block
     (2, 1, 96, 40, 40, False, 0),         # search space = 5/6 of the matrix
+    (4, 1, 9, 2, 2, False, 0),            # the reference's block rule leaves the LAST grid row without rows: 3, 3, 3, 0
+    (4, 2, 9, 2, 2, True, 0),             # ... and with two grid columns (5 + 4 columns)
+    (3, 2, 4, 1, 1, False, 0),            # rows 2, 2, 0 and columns 2, 2
 ])
 def test_solve_on_awkward_grids_and_sizes(nprow, npcol, N, nev, nex, cplx, mb):
     from rank_threads import run_ranks as run_grid
