@@ -344,8 +344,7 @@ def scenario_qr_fixtures(ctx, grid, comm, cplx, mb=0):
 
 
 def scenario_reference_run_counts(ctx, grid, comm):
-    """The reference's own example run, measured with the actual reference binary (BASELINE.md "Cross-check measured with
-    the actual reference"): examples/1_hello_world, pChASECPU, unperturbed complex Clement N = 1200, nev = 80, nex = 60,
+    """The example run of the survey's cross-check table (consistency counts, not pins): examples/1_hello_world, pChASECPU, unperturbed complex Clement N = 1200, nev = 80, nex = 60,
     block-cyclic nb = 64 on a 2 x 2 grid, start vectors mt19937(1337 + grid row) -> 6 iterations, 13 310 filtered vectors,
     eigenvalues -N, -N+2, ..."""
     rank, world = comm.rank, comm.world

@@ -78,9 +78,9 @@ def test_pseudo_solve_4x2_eight_ranks():
     run(8, S.scenario_pseudo_solve, 0)
 
 
-def test_distributed_run_reproduces_the_reference_example_run():
-    """examples/1_hello_world measured with the actual reference (pChASECPU, 2 x 2, block-cyclic nb = 64): 6 iterations,
-    13 310 filtered vectors (BASELINE.md cross-check table)"""
+def test_distributed_run_reproduces_the_survey_cross_check_counts():
+    """examples/1_hello_world in the survey's cross-check table (pChASECPU, 2 x 2, block-cyclic nb = 64): 6 iterations,
+    13 310 filtered vectors - consistency counts, not pins (tests/test_oracle_pins.py)"""
     run(4, S.scenario_reference_run_counts)
 
 
@@ -115,7 +115,7 @@ def test_grid_sendrecv_and_exact_agree_max(nranks):
     (2, 1, 96, 40, 40, False, 0),         # search space = 5/6 of the matrix
     (4, 1, 9, 2, 2, False, 0),            # the reference's block rule leaves the LAST grid row without rows: 3, 3, 3, 0
     (4, 2, 9, 2, 2, True, 0),             # ... and with two grid columns (5 + 4 columns)
-    (3, 2, 4, 1, 1, False, 0),            # rows 2, 2, 0 and columns 2, 2
+    (5, 1, 16, 3, 3, True, 0),            # five grid rows: 4, 4, 4, 4, 0
 ])
 def test_solve_on_awkward_grids_and_sizes(nprow, npcol, N, nev, nex, cplx, mb):
     from rank_threads import run_ranks as run_grid

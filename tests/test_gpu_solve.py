@@ -272,8 +272,9 @@ def test_reinit_columns_hook(ctx, cplx):
 
 
 @pytest.mark.parametrize("N,cplx,nev,nex,iters,vecs", [(4096, False, 100, 40, 8, 24988), (1200, True, 80, 60, 5, 12664)])
-def test_hip_path_reproduces_runs_of_the_actual_reference(ctx, N, cplx, nev, nex, iters, vecs):
-    """The same two runs of the reference binary (BASELINE.md cross-check table) through the HIP Impl with the reference's
+def test_hip_path_reproduces_the_survey_cross_check_counts(ctx, N, cplx, nev, nex, iters, vecs):
+    """The survey's cross-check counts (consistency counts, not pins - see tests/test_oracle_pins.py) through the
+    HIP Impl with the reference's
     start-vector generator: identical iteration and filtered-vector counts."""
     from chase_amd.capi import Solver
     s = Solver(ctx, O.clement(N, cplx, perturb=0), nev, nex)
