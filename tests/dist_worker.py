@@ -9,6 +9,17 @@ import sys
 import faulthandler
 
 faulthandler.enable()
+if os.environ.get("CHASE_TEST_FAKE_HOSTS") == "1":
+    # Real RCCL collectives between ranks on a ONE-GPU box: RCCL refuses two ranks of a communicator on one device of one
+    # host ("Duplicate GPU detected"), but it tells hosts apart by NCCL_HOSTID - give every rank process its own "host" and
+    # the ranks talk through RCCL's socket transport over loopback (slow, but every ncclAllReduce / ncclBroadcast /
+    # ncclSend / ncclRecv of the grid really runs between distinct ranks).  Must be set before the first RCCL call.
+    os.environ["NCCL_HOSTID"] = "chase-test-host-" + os.environ.get("RANK", "0")
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
+    os.environ.setdefault("NCCL_NET", "Socket")
+    os.environ.setdefault("NCCL_SHM_DISABLE", "1")
+    os.environ.setdefault("NCCL_P2P_DISABLE", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
