@@ -207,7 +207,10 @@ def run_rank(args, comm, ctx, grid, mode):
                                       else "perturbed Clement-type Hermitian (x100/N)") + f" N={N} "
                                    f"{'complex' if cplx else 'real'} fp64, nev={nev} nex={nex}, tol 1e-10, deg 20 opt, "
                                    f"{nprow}x{npcol} {'block-cyclic nb=%d' % nb if nb else 'block'} grid, "
-                                   + ("RCCL over xGMI" if is_rccl else "host-callback TEST transport - not a measurement of RCCL")
+                                   + (("RCCL over xGMI" if os.environ.get("CHASE_BENCH_FAKE_HOSTS") != "1" else
+                                       "RCCL over its SOCKET transport between rank processes sharing one GPU (NCCL_HOSTID per rank): "
+                                       "a functional rehearsal, not a measurement") if is_rccl
+                                      else "host-callback TEST transport - not a measurement of RCCL")
                                    + f", ranks = {mode}"
                                    + "; step = one outer iteration (filter+QR+RR+residuals+locking), solves back to back",
                        "N": N, "nev": nev, "nex": nex, "grid": f"{nprow}x{npcol}", "step": "outer iteration",

@@ -586,7 +586,15 @@ protected:
         const std::size_t in_ld = bAc ? m_ : n_;
         const T* Hb = bAc ? dHbac_ : dH_;
         const std::size_t ldb = bAc ? ldhbac_ : ldh_;
-        const bool pipe = pipelined && pipeline_ && chase_hip_grid_group_active(grid_, group) != 0;
+        // Two separate questions.  `active`: does THIS direction have a collective (its group has more than one member)?
+        // `panels`: is the product cut on the panel grid and ordered by the per-panel events?  It must be whenever EITHER
+        // direction's collective runs asynchronously on the communication stream: my input panels are the output of the
+        // previous product of the OTHER direction, whose all-reduces may still be in flight - also when my own group has a
+        // single member (2 x 1 grid: the row group; round 4 found exactly this with the first real RCCL run between two
+        // ranks: the row -> column product read W before the column group's all-reduce had landed).
+        const bool active = chase_hip_grid_group_active(grid_, group) != 0;
+        const bool other_active = chase_hip_grid_group_active(grid_, bAc ? CHASE_HIP_ROW : CHASE_HIP_COL) != 0;
+        const bool pipe = pipelined && pipeline_ && (active || other_active);
         // the panel products run beside the previous panel's all-reduce: finer work units, so that the CUs the collective
         // takes displace a fraction of a tile (chase_hip_ctx_set_gemm_min_rounds; CHASE_HIP_PANEL_ROUNDS, 0 = off)
         static const int panel_rounds = [] { const char* e = std::getenv("CHASE_HIP_PANEL_ROUNDS"); return e ? std::atoi(e) : 4; }();
@@ -605,8 +613,12 @@ protected:
             if (pipe) coll(chase_hip_grid_event_wait(grid_, (int)fp));         // previous step's all-reduce of my input
             if (bAc) gemm('C', n_, w, m_, alpha, Hb, ldb, in + c * in_ld, in_ld, b, out + c * out_ld, out_ld);
             else     gemm('N', m_, w, n_, alpha, Hb, ldb, in + c * in_ld, in_ld, b, out + c * out_ld, out_ld);
-            coll(chase_hip_grid_allreduce(grid_, group, out + c * out_ld, out_ld * w * E, pipe ? 1 : 0));
-            if (pipe) coll(chase_hip_grid_event_record(grid_, (int)fp));
+            if (active) {
+                coll(chase_hip_grid_allreduce(grid_, group, out + c * out_ld, out_ld * w * E, pipe ? 1 : 0));
+                // (an inactive direction records nothing: its output panel is ordered by the compute stream itself, and the
+                // slot keeps the other direction's last event, which this product has already waited for)
+                if (pipe) coll(chase_hip_grid_event_record(grid_, (int)fp));
+            }
             c = cend;
         }
     }

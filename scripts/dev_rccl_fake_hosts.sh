@@ -11,5 +11,5 @@ timeout -k 10 ${FAKE_TIMEOUT:-240} python -m torch.distributed.run --nnodes=1 --
     $REPO/tests/dist_worker.py rccl "$@" > $REPO/gpurun_out/rccl_fake_hosts_$SCEN.log 2>&1
 rc=$?
 echo "fake-hosts $N ranks $* -> rc=$rc"
-grep -E "DIST_WORKER_OK|NCCL WARN|Duplicate|Error|error|via NET|Channel 00" $REPO/gpurun_out/rccl_fake_hosts_$SCEN.log | head -${LINES_SHOWN:-12}
+grep -E "DIST_WORKER_OK|NCCL WARN|Duplicate|Error|error|via NET|Channel 00|NOTE|note:|pseudo solve:" $REPO/gpurun_out/rccl_fake_hosts_$SCEN.log | head -${LINES_SHOWN:-12}
 exit $rc

@@ -233,6 +233,11 @@ def scenario_solve(ctx, grid, comm, N, nev, nex, cplx, mb, deg, same_iterations=
     for (i, j, blk) in objs:
         if j == 0:
             V[rl.globals_of(i), :] = blk
+    # the replicas of the eigenvector block over the grid columns agree bit for bit (the reference re-broadcasts V inside the row
+    # group before Rayleigh-Ritz for this, pchase_gpu.hpp:1631-1633; with real RCCL the two column communicators may sum
+    # their Gram matrices in different orders)
+    for (i, j, blk) in objs:
+        assert np.array_equal(V[rl.globals_of(i), :], blk), "column-type replicas differ"
     r_host = O.residuals(H, lam, V)
     assert np.max(r_host) < 1e-8
     r_dev = s.recompute_residuals(nev)               # mpi/residuals.hpp on the grid, from a fresh four-product H V
@@ -479,6 +484,8 @@ def scenario_pseudo_solve(ctx, grid, comm, mb):
     st = s.solve()
     lam = s.ritzv[:nev].copy()
     resid = s.resid()[:nev]
+    note(f"pseudo solve: iterations {st['iterations']} filtered {st['filtered_vecs']} locked {st['locked']} "
+         f"max resid {np.max(resid):.4e} max |lam - ref| {np.max(np.abs(lam - pos[:nev])):.3e}")
     assert np.all(np.isfinite(lam)) and np.all(np.isfinite(resid))
     assert np.max(resid) <= 1e-10
     V = gathered_V(s, grid, rl, comm, N, H.dtype)[:, :nev]

@@ -73,6 +73,22 @@ def test_thread_per_gpu_mode_on_one_gpu():
     assert d["iterations_per_solve"] == 9 and d["transport_proof"]["ok"]
 
 
+@pytest.mark.parametrize("ngpus,grid", [(2, "2x1"), (4, "2x2")])
+def test_multi_rank_bench_with_real_rccl_collectives(ngpus, grid):
+    """`bench.py --gpus N` end to end over REAL RCCL communicators of more than one rank (CHASE_BENCH_FAKE_HOSTS=1: one
+    NCCL_HOSTID per rank process, socket transport, all ranks on this box's one GPU): the transport proof, the timed solves with
+    the panel-pipelined all-reduces on the communication stream, the exposed-communication brackets, the independent residuals
+    and the communication probe - a functional rehearsal of the multi-GPU run (the numbers say nothing about xGMI)."""
+    d = run_bench("--gpus", str(ngpus), "--workload", "cfg2", "--n", "8192", "--steps", "6", "--warmup", "0", "--no-cpu-baseline",
+                  env={"CHASE_BENCH_FAKE_HOSTS": "1"})
+    check_common(d, ngpus, 6, 0)
+    assert d["config"]["grid"] == grid and d["config"]["transport"] == "rccl" and "SOCKET transport" in d["config"]["workload"]
+    assert d["ranks_seen_by_rccl"]["grid"] == ngpus                           # what ncclCommCount itself reports
+    assert d["transport_proof"]["col_group"]["ranks"] == 2 and d["transport_proof"]["col_group"]["busbw_GBps"] > 0
+    assert d["comm_waits"] > 0 and d["comm_exposed_ms"] > 0                      # the compute stream really waited on collectives
+    assert d["comm_probe"]["col_group_panel_allreduce"]["ranks"] == 2
+
+
 def test_rank_of_a_torchrun_launch_on_one_gpu():
     """the driver's multi-GPU call: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` - bench.py is then one
     of the ranks (RANK set by the launcher).  Two ranks sharing this box's one GPU through the host test transport (which

@@ -2,6 +2,7 @@
 never hide the in-process suite again.  Never more than 4 worker processes + this pytest process hold the GPU (box limit: 6).
 * the RCCL transport through size-1 communicators in a fresh process (ncclCommInitRank / ncclAllReduce / ncclBroadcast, the
   communication stream and per-panel events);
+* REAL RCCL collectives between 2 and 4 rank processes that share the GPU (one NCCL_HOSTID per rank -> RCCL's socket transport);
 * one 4-process host-transport run (the torch.distributed/gloo fabric bench.py's launcher and dist_bench use);
 * the reference's MPI_Comm* entry points (libchase_hip_mpi.so) on one MPI rank, and the plain-C MPI example."""
 import os
@@ -38,6 +39,37 @@ def test_rccl_forced_through_size1_communicators():
     run_ranks(1, "rccl", "ops", "d", 0, env_extra=force)
     run_ranks(1, "rccl", "pseudo_solve", 0, env_extra=force)
     run_ranks(1, "rccl", "pseudo_ops", 0, env_extra=force)
+
+
+FAKE_HOSTS = {"CHASE_TEST_FAKE_HOSTS": "1"}
+
+
+def test_real_rccl_collectives_between_two_ranks():
+    """ncclAllReduce / ncclBroadcast / ncclSend / ncclRecv between DISTINCT ranks (round 4: the first time in any round).  RCCL
+    refuses two ranks of a communicator on one device of one host, but tells hosts apart by NCCL_HOSTID: every rank process gets
+    its own (tests/dist_worker.py) and the ranks - sharing this box's one GPU - talk through RCCL's socket transport.  Slow,
+    but it is the production transport code of grid.hip end to end: the communication stream, the per-panel events of the
+    pipelined HEMM, the packed broadcasts of the redistribution, the pairwise K-conjugation exchange, the agreement
+    collectives.  The 2 x 1 grid is where the first run found a real race (the row -> column product of a grid with ONE column
+    did not wait for the column group's all-reduce of its input, pchase_hip_impl.hpp hemm_ptr) - invisible to the synchronous
+    host transport and to size-1 communicators."""
+    run_ranks(2, "rccl", "p2p", env_extra=FAKE_HOSTS)
+    run_ranks(2, "rccl", "ops", "z", 16, env_extra=FAKE_HOSTS)
+    run_ranks(2, "rccl", "solve", 1001, 100, 60, "z", 64, 20, env_extra=FAKE_HOSTS)
+    run_ranks(2, "rccl", "pseudo_ops", 0, env_extra=FAKE_HOSTS)
+    run_ranks(2, "rccl", "pseudo_solve", 0, env_extra=FAKE_HOSTS)
+    run_ranks(2, "rccl", "qr_fixtures", "d", 0, env_extra=FAKE_HOSTS)
+    run_ranks(2, "rccl", "cshim", "z", 16, env_extra=FAKE_HOSTS)
+
+
+def test_real_rccl_collectives_on_the_2x2_grid():
+    """the same with four rank processes (row AND column communicators of two ranks each): operators, a block-cyclic solve
+    whose eigenvector replicas must agree bit for bit across the two column communicators, the pseudo-Hermitian path, the
+    distributed Householder QR"""
+    run_ranks(4, "rccl", "ops", "d", 0, env_extra=FAKE_HOSTS)
+    run_ranks(4, "rccl", "solve", 1001, 100, 60, "d", 64, 20, env_extra=FAKE_HOSTS)
+    run_ranks(4, "rccl", "pseudo_solve", 0, env_extra=FAKE_HOSTS)
+    run_ranks(4, "rccl", "qr_fixtures", "z", 0, env_extra=FAKE_HOSTS)
 
 
 def test_four_processes_share_the_gpu_through_gloo():
