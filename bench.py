@@ -539,8 +539,9 @@ PROBE_TIMEOUT_S = float(os.environ.get("CHASE_BENCH_PROBE_TIMEOUT", "240"))
 def fake_hosts(env):
     """CHASE_BENCH_FAKE_HOSTS=1: a functional rehearsal of the multi-GPU run with REAL RCCL collectives on a box with ONE GPU.
     RCCL refuses two ranks of a communicator on one device of one host, but tells hosts apart by NCCL_HOSTID: every rank process
-    gets its own "host" and the ranks talk through RCCL's socket transport over loopback, all on device 0 (tests only: the
-    numbers say nothing about xGMI, and the transport proof's bar is lowered to 0)"""
+    gets its own "host" and the ranks talk through RCCL's socket transport over loopback, all on the box's one device (the
+    binding wraps local ranks onto the devices there are).  Tests only: the numbers say nothing about xGMI, and the transport
+    proof's bar is lowered to 0.  The mode selection runs as in a real job - probe children, real communicators."""
     return env.get("CHASE_BENCH_FAKE_HOSTS") == "1"
 
 
@@ -554,7 +555,6 @@ def mode_env(env, mode, local_rank):
         for k, v in (("NCCL_SOCKET_IFNAME", "lo"), ("NCCL_IB_DISABLE", "1"), ("NCCL_NET", "Socket"), ("NCCL_SHM_DISABLE", "1"),
                      ("NCCL_P2P_DISABLE", "1"), ("CHASE_HIP_MIN_BUSBW_GBPS", "0")):
             env.setdefault(k, v)
-        mode = "unbound"
     if mode == "bound":
         env["CHASE_HIP_BIND"] = "1"
         bind_one_device(env, local_rank)
@@ -731,12 +731,12 @@ def main():
         mode = "unbound"                                 # (round 3's switch, kept)
     if args.gpus > 1 and not launched:
         if mode is None:
-            mode = "bound" if host_transport else ("unbound" if fake_hosts(os.environ) else choose_mode_as_parent(args, argv))
+            mode = "bound" if host_transport else choose_mode_as_parent(args, argv)
         if mode != "threads":
             sys.exit(spawn_ranks(args, argv, mode))
     elif launched and world > 1 and not args.transport_probe:
         if mode is None:
-            mode = "bound" if host_transport else ("unbound" if fake_hosts(os.environ) else choose_mode_as_rank(args, argv))
+            mode = "bound" if host_transport else choose_mode_as_rank(args, argv)
         if mode == "threads" and int(os.environ["RANK"]) != 0:
             return                                       # rank 0 hosts the threads; this rank never touches the GPU
         if mode in ("bound", "unbound"):

@@ -89,6 +89,22 @@ def test_multi_rank_bench_with_real_rccl_collectives(ngpus, grid):
     assert d["comm_probe"]["col_group_panel_allreduce"]["ranks"] == 2
 
 
+def test_launcher_ranks_settle_their_mode_with_real_probe_children():
+    """the driver's multi-GPU call (`torch.distributed.run ... bench.py --gpus 2`) with `--ranks auto` and REAL RCCL (fake hosts):
+    every rank starts its own probe child, the children build real communicators on their own port, run the 256 MB proof and
+    agree; the ranks then bind and run the bench in the mode the probe passed"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29741", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg2", "--size", "4096", "--steps", "4",
+           "--warmup", "1", "--no-cpu-baseline", "--no-probe"]      # (--size: the launcher's own parser claims "--n...")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CHASE_BENCH_FAKE_HOSTS="1"))
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    assert "probe of mode 'bound': exit status 0" in p.stderr and "bench probe [processes, one visible device each]" in p.stderr
+    d = json.loads([l for l in p.stdout.strip().splitlines() if l.startswith("{")][-1])
+    check_common(d, 2, 4, 1)
+    assert d["config"]["ranks"] == "processes, one visible device each" and d["ranks_seen_by_rccl"]["grid"] == 2
+
+
 def test_rank_of_a_torchrun_launch_on_one_gpu():
     """the driver's multi-GPU call: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` - bench.py is then one
     of the ranks (RANK set by the launcher).  Two ranks sharing this box's one GPU through the host test transport (which
