@@ -922,6 +922,8 @@ static ColsPlan plan_cols(int m, int n, int k, bool have_ws)
         if (mode != 0 && rem <= 64) {
             // cheaper than letting a partly idle 128-wide last tile ride along at a whole tile's cost? (fit of the numbers
             // above: 0.75 passes over A + 0.68 of a group's whole-tile time per live group)
+            // (75 TFLOP/s and 5.5 TB/s are FIXED model constants, not read from the device: the choice sets the launch
+            // decomposition and with it the summation order, which must not differ between the devices of one job)
             const double t_group = 2.0 * m * (double)k * 16.0 / 75.0e12;
             const double t_pass = (double)m * k * 8.0 / 5.5e12;
             const int g = (rem + 15) / 16;
@@ -961,7 +963,7 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
     // gemm_f64_ws_need, which takes its numbers from the same plan
     PartPlan pl = plan_part<CPLX, OPA_C, NARROW>(m, n, k, bn_cols, num_cu, li.min_rounds);
     if (ws == nullptr) pl = PartPlan{(long)a.gm * a.gn, 0, 1, 0};
-    if (pl.ws_bytes > ws_bytes) return (int)hipErrorInvalidValue;       // never split differently to fit: refuse
+    if (pl.ws_bytes > ws_bytes) return GEMM_F64_EWORKSPACE;             // never split differently to fit: refuse (distinct code)
     const long full = pl.full, tail = pl.tail;
     const int sk = pl.sk;
     int kchunk = ((nkt + sk - 1) / sk) * C_::BK;

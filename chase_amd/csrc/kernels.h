@@ -17,6 +17,9 @@ int gemm_f64(hipStream_t st, bool cplx, char opA, int m, int n, int k, const dou
              int num_cu, int tag = 0, int device = 0, double* exec_flops = nullptr, int min_rounds = 0);
 constexpr size_t GEMM_WS_CAP = (size_t)640 << 20;         // upper bound of the split-K workspace
 size_t gemm_f64_ws_need(bool cplx, char opA, int m, int n, int k, int num_cu, int min_rounds = 0);
+// gemm_f64's status when the caller's split-K workspace is smaller than gemm_f64_ws_need says for the shape (the launcher
+// never picks another split to fit: the summation order of a shape must not depend on allocation history)
+constexpr int GEMM_F64_EWORKSPACE = -77001;
 int gemm3m_enabled();
 void gemm3m_set(int on);
 

@@ -17,6 +17,8 @@ int chase_hip_ctx::gemm(bool cplx, char opA, int m, int n, int k, const double* 
     const int ph = (phase >= 0 && phase <= 3) ? phase : 0;
     int e = chase_hip::gemm_f64(stream, cplx, opA, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, (double*)ws, ws_bytes,
                                 num_cu, phase, device, &flops_exec[ph], gemm_min_rounds);
+    if (e == chase_hip::GEMM_F64_EWORKSPACE)
+        return chase_hip::set_error(CHASE_HIP_EINVAL, "gemm: split-K workspace smaller than gemm_f64_ws_need for this shape");
     if (e) return chase_hip::hip_fail((hipError_t)e, "gemm launch");
     flops_model[ph] += 2.0 * (cplx ? 4.0 : 1.0) * m * (double)n * k;
     ++gemm_calls[ph];

@@ -62,6 +62,14 @@ def test_real_rccl_collectives_between_two_ranks():
     run_ranks(2, "rccl", "cshim", "z", 16, env_extra=FAKE_HOSTS)
 
 
+def test_real_rccl_collectives_in_a_three_rank_column_group():
+    """3 x 1: three-member communicators (RCCL's ring / tree with an odd member count), the K-conjugation partners two grid rows
+    away, block-cyclic rows of the distributed Householder"""
+    run_ranks(3, "rccl", "ops", "z", 0, env_extra=FAKE_HOSTS)
+    run_ranks(3, "rccl", "pseudo_solve", 0, env_extra=FAKE_HOSTS)
+    run_ranks(3, "rccl", "qr_fixtures", "d", 16, env_extra=FAKE_HOSTS)
+
+
 def test_real_rccl_collectives_on_the_2x2_grid():
     """the same with four rank processes (row AND column communicators of two ranks each): operators, a block-cyclic solve
     whose eigenvector replicas must agree bit for bit across the two column communicators, the pseudo-Hermitian path, the
