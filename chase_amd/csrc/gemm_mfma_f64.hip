@@ -427,7 +427,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
             constexpr int NA = C_::A_GLDS / 4, NB = C_::B_GLDS / 4;
             const char* sa[NA];                                 // uniform
             unsigned va[NA];                                    // per lane, bytes
-            const char* sb = (const char*)(p.B + ((long)col0 * p.ldb + kbeg) * EPT);
+            // diagnostic builds (timing only, results wrong on purpose; scripts/dev_build_variant.sh): every workgroup streams
+            // the SAME A row panel / the same B column panel, so that operand is served by the L2s - what would a launch gain if
+            // its re-reads never left the L2?  (profiles/r04_traffic_upper_bound.txt)
+#ifdef CHASE_DIAG_SAME_A
+            const int row0_src = 0;
+#else
+            const int row0_src = row0;
+#endif
+#ifdef CHASE_DIAG_SAME_B
+            const int col0_src = 0;
+#else
+            const int col0_src = col0;
+#endif
+            const char* sb = (const char*)(p.B + ((long)col0_src * p.ldb + kbeg) * EPT);
             unsigned vb[NB];
             #pragma unroll
             for (int u = 0; u < NA; ++u) {
@@ -435,11 +448,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                 if constexpr (!OPA_C) {
                     // [k][unit] image: complex 128 units per k row (two instructions), real 64 units (one)
                     const int kk = CPLX ? (t >> 1) : t, half = CPLX ? (t & 1) : 0;
-                    sa[u] = (const char*)(p.A + ((long)(kbeg + kk) * p.lda + row0) * EPT + (long)half * 128);
+                    sa[u] = (const char*)(p.A + ((long)(kbeg + kk) * p.lda + row0_src) * EPT + (long)half * 128);
                     va[u] = (unsigned)lane * 16u;
                 } else {
                     const int r = 8 * t + (lane >> 3), ku = (lane & 7) ^ ((r >> 1) & 7);
-                    sa[u] = (const char*)(p.A + ((long)row0 * p.lda + kbeg) * EPT);
+                    sa[u] = (const char*)(p.A + ((long)row0_src * p.lda + kbeg) * EPT);
                     va[u] = (unsigned)(((long)r * p.lda + ku * KPU) * EPT * 8);
                 }
             }
