@@ -324,9 +324,12 @@ public:
         if (resync && npcol_ > 1) coll(chase_hip_grid_bcast(grid_, CHASE_HIP_ROW, dV1_ + c0 * m_, m_ * block * E, 0, 0));
         hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)block, dV1_ + c0 * m_, (long)m_, dV2_ + c0 * m_, (long)m_), "lacpy");
         chase_hip_ctx_set_phase(ctx_, 2);                                    // H-times-block product outside the filter
-        hemm_dir(true, c0, block, T(1), T(0), false);                        // W1 = H^H V1 (row-type), all-reduced
+        // panel-pipelined like the filter's products (round 4): the all-reduce of column panel p (1.34 GB in all at config 4 on
+        // 4 x 2) runs beside the GEMM of panel p + 1; the redistribution below queues behind it on the communication stream
+        // and its wait covers both
+        hemm_dir(true, c0, block, T(1), T(0), true);                         // W1 = H^H V1 (row-type), all-reduced
         chase_hip_ctx_set_phase(ctx_, 0);
-        redistribute_c2r(dV2_ + c0 * m_, dW2_ + c0 * n_, block);             // W2 = V2 in the row-type layout
+        redistribute_c2r(dV2_ + c0 * m_, dW2_ + c0 * n_, block);             // W2 = V2 in the row-type layout (waits for the stream)
         // A = V^H (H V), Hermitian: only the upper block trapezoid is multiplied, packed and summed over the row group
         hip_ok(chase_hip_herkx(ctx_, CP, (int)block, (int)n_, dW2_ + c0 * n_, (long)n_, dW1_ + c0 * n_, (long)n_, dA_, (long)block, 0), "herkx");
         allreduce_packed_upper(dA_, block, CHASE_HIP_ROW);
@@ -356,9 +359,9 @@ public:
             HV = dW3_ + c0 * n_; Vr = dW1_ + c0 * n_;
         } else {
             chase_hip_ctx_set_phase(ctx_, 2);
-            hemm_dir(true, c0, sub, T(1), T(0), false);                      // W1 = H^H V1
+            hemm_dir(true, c0, sub, T(1), T(0), true);                       // W1 = H^H V1 (panel-pipelined, see RR)
             chase_hip_ctx_set_phase(ctx_, 0);
-            redistribute_c2r(dV2_ + c0 * m_, dW2_ + c0 * n_, sub);           // W2 = V2 (== V1) row-type
+            redistribute_c2r(dV2_ + c0 * m_, dW2_ + c0 * n_, sub);           // W2 = V2 (== V1) row-type (waits for the stream)
             HV = dW1_ + c0 * n_; Vr = dW2_ + c0 * n_;
             hv_valid_ = false;                                               // dW1_ no longer holds the cached V
         }
