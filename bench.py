@@ -533,7 +533,7 @@ def bind_one_device(env, local_rank):
 # communicators, the 256 MB all-reduce proof) started before this process has touched the GPU; the first mode whose probe
 # exits 0 runs the bench.  A mode is never switched inside a process that has initialised HIP.
 MODES = ("bound", "unbound", "threads")
-PROBE_TIMEOUT_S = float(os.environ.get("CHASE_BENCH_PROBE_TIMEOUT", "240"))
+PROBE_TIMEOUT_S = float(os.environ.get("CHASE_BENCH_PROBE_TIMEOUT", "150"))
 
 
 def fake_hosts(env):
@@ -575,7 +575,7 @@ def run_children(cmds_envs, timeout_s):
     processes started here).  Returns the first non-zero exit status (124 for a timeout), else 0."""
     procs = [subprocess.Popen(argv, env=env, stdout=out if out is not None else sys.stderr, stderr=sys.stderr)
              for argv, env, out in cmds_envs]
-    rc, t0 = 0, time.perf_counter()
+    rc, t0, term_at = 0, time.perf_counter(), None
     try:
         alive = set(range(len(procs)))
         while alive:
@@ -589,12 +589,18 @@ def run_children(cmds_envs, timeout_s):
                     print(f"bench: rank {r} exited with status {code}; stopping the other ranks", file=sys.stderr)
                     for q in alive:
                         procs[q].terminate()
+                    term_at = term_at or time.perf_counter()
             if alive and timeout_s and time.perf_counter() - t0 > timeout_s:
                 print(f"bench: ranks still running after {timeout_s:.0f} s; stopping them", file=sys.stderr)
                 rc = rc or 124
                 for q in alive:
                     procs[q].terminate()
+                term_at = term_at or time.perf_counter()
                 timeout_s = None
+            if alive and term_at and time.perf_counter() - term_at > 15.0:
+                for q in alive:                         # a rank that ignores SIGTERM (stuck in a collective): exactly these pids
+                    procs[q].kill()
+                term_at = time.perf_counter()
             time.sleep(0.2)
     finally:
         for p in procs:
