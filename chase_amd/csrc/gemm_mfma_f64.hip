@@ -630,11 +630,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                     cluster(stn, 0, yes, fill_c, st);                          // chunk 1 of tile kt (+ the copies of tile kt+STAGES)
                 };
                 int kt = 0;
-                // (not for the ragged op = C instantiation: the loop-invariant address registers of the unrolled form are what
-                // pushed it one register over 256 - a spill in the K loop; its launches are 1 % of a solve's filter time)
-                if constexpr (C_::STAGES == 3 && !(RAGGED && OPA_C)) {
-                    // steady state, three K steps per trip: the stage indices are compile-time constants, so every LDS
-                    // address is a loop-invariant register plus an immediate offset (no address arithmetic in the loop)
+                // steady state, three K steps per trip: the stage indices are compile-time constants, so every LDS address is a
+                // loop-invariant register plus an immediate offset (no address arithmetic in the loop).  In the two ragged op = C
+                // instantiations this form parks ONE VGPR in scratch across the K loop (one store before the loops, one load after
+                // them - tests/test_kernel_resources.py checks that no scratch access sits inside a loop); the form without the
+                // unrolled loop needs no scratch but runs all-ragged launches 3 % slower (profiles/r04_ragged_c_compare.txt), so the
+                // unrolled form stays.  -DCHASE_NO_RAGGED_C_UNROLL builds the comparison.
+#ifdef CHASE_NO_RAGGED_C_UNROLL
+                constexpr bool unroll3 = (C_::STAGES == 3) && !(RAGGED && OPA_C);
+#else
+                constexpr bool unroll3 = (C_::STAGES == 3);
+#endif
+                if constexpr (unroll3) {
                     for (; kt + 2 + C_::STAGES < nfull; kt += 3) {
                         kstep(kt, 0, yes);
                         kstep(kt + 1, 1, yes);
