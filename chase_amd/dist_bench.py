@@ -157,6 +157,8 @@ def run_rank(args, comm, ctx, grid, mode):
         ctx.sync()
         s = cd.DistSolver(ctx, grid, dH, N, nev, nex, cplx, mb, nb)
         s.set(device_rng=1)
+    if os.environ.get("CHASE_HIP_PIPELINE") == "0":
+        s.set(pipeline=0)            # development: every all-reduce waited for where it is issued (what the overlap is worth)
 
     def snapshot():
         model, execd, calls = gemm_counters(ctx, 1)
