@@ -16,14 +16,34 @@ _PORT = [29611]
 
 
 def run_ranks(nranks, transport, *args, timeout=600, env_extra=None):
+    """Starts the rank processes directly (RANK / WORLD_SIZE / MASTER_* like torch.distributed.run sets them; rank 0 hosts the
+    rendezvous store): a launcher process of its own would be one more process holding the GPU (it imports torch), and the box
+    allows six - pytest + four ranks must stay below that."""
     assert nranks <= 4, "box limit: at most 6 processes with the GPU open, pytest itself is one of them"
     _PORT[0] += 1
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_PORT[0]),
-           os.path.join(ROOT, "tests", "dist_worker.py"), transport, *map(str, args)]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", **(env_extra or {}))
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
-    assert p.returncode == 0 and "DIST_WORKER_OK" in p.stdout, (p.stdout[-3000:], p.stderr[-3000:])
+    import tempfile
+    procs, files = [], []
+    for r in range(nranks):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", RANK=str(r), LOCAL_RANK=str(r),
+                   WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_PORT[0]),
+                   **(env_extra or {}))
+        fo, fe = tempfile.TemporaryFile(mode="w+"), tempfile.TemporaryFile(mode="w+")      # (files, not pipes: nobody blocks on output)
+        files.append((fo, fe))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), transport, *map(str, args)],
+                                      stdout=fo, stderr=fe, env=env, cwd=ROOT))
+    try:
+        for p in procs:
+            p.wait(timeout=timeout)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                               # exactly the processes started above
+    outs = []
+    for fo, fe in files:
+        fo.seek(0); fe.seek(0)
+        outs.append((fo.read(), fe.read()))
+    ok = all(p.returncode == 0 for p in procs) and "DIST_WORKER_OK" in outs[0][0]
+    assert ok, [(p.returncode, o[0][-1500:], o[1][-2500:]) for p, o in zip(procs, outs)]
 
 
 def test_solve_rccl_transport_single_rank():
