@@ -4,7 +4,8 @@ ARCH  ?= gfx950
 CSRC  := chase_amd/csrc
 HOST  := chase_amd/host
 OUT   := chase_amd/lib/libchase_hip.so
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I/opt/rocm/include -I$(CSRC) -I$(HOST) -Wno-unused-result -Wno-unused-value
+EXTRA ?=
+HIPFLAGS := $(EXTRA) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I/opt/rocm/include -I$(CSRC) -I$(HOST) -Wno-unused-result -Wno-unused-value
 SRCS  := $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp) $(wildcard $(HOST)/*.cpp)
 OBJS  := $(patsubst %,build/%.o,$(SRCS))
 HDRS  := $(wildcard include/*.h) $(wildcard $(CSRC)/*.h) $(wildcard $(HOST)/*.hpp)

@@ -21,7 +21,7 @@ struct chase_hip_ctx {
     int gemm_min_rounds = 0;          // > 0: products share the chip with a collective (chase_hip_ctx_set_gemm_min_rounds)
     void* ws = nullptr;          // split-K slabs, grown on demand
     size_t ws_bytes = 0;
-    enum { BUF_TINV = 0, BUF_PANEL, BUF_SCAL, BUF_LAMBDA, BUF_RR, BUF_EIG, BUF_STEDC, NBUF };
+    enum { BUF_TINV = 0, BUF_PANEL, BUF_SCAL, BUF_LAMBDA, BUF_RR, BUF_EIG, BUF_STEDC, BUF_APPLYQ, NBUF };
     void* bufs[NBUF] = {};   // device scratch, grown on demand (BUF_EIG / BUF_STEDC: the projected eigensolver's blocks)
     size_t buf_bytes[NBUF] = {};
     void* hstage = nullptr;      // pinned host staging (HEEVD round trip)

@@ -203,7 +203,10 @@ __global__ __launch_bounds__(256) void trd_her2_kernel(double* __restrict__ A, l
 //            extra workgroups of the same launch: V^H v and W^H v (2 jj dot products)
 //   w        p = sum(part) - V (W^H v) - W (V^H v), w = tau p, partial w^H v; reflector into A's column
 // X = [V | W] is the panel buffer (n rows, global row index, zero above the reflector heads).
-constexpr int LNB = 32;
+#ifndef CHASE_LNB
+#define CHASE_LNB 32
+#endif
+constexpr int LNB = CHASE_LNB;   // panel width of the blocked tridiagonalisation (32; 64 is slower: 71.8 against 63.1 ms at n = 2560, profiles/r04_heevd.txt)
 constexpr int LTCW = 128; // largest column chunk of the blocked reduction's GEMV (the host picks 64 or 128: fewer partials to re-add
                           // for large trailing blocks, enough workgroups for small ones)
 

@@ -331,39 +331,95 @@ static int g3(chase_hip_ctx* c, bool cplx, char op, int m, int n, int k, double 
 }
 
 namespace chase_hip {
+// T_ss of every HNB-wide sub-block s of an aggregated block (LAPACK xLARFT forward / columnwise inside the sub-block) from the
+// block's Gram matrix G = V^H V (nbig x nbig, ld ldg): written into T (ld ldt) at (HNB s, HNB s).  One wave per sub-block.
+template <bool CPLX>
+__global__ __launch_bounds__(64) void larft_diag_kernel(const double* __restrict__ G, int ldg, int nbig,
+                                                        const double* __restrict__ tau, double* __restrict__ T, int ldt)
+{
+    constexpr int E = CPLX ? 2 : 1;
+    __shared__ double t[HNB * HNB * 2];
+    __shared__ double g[HNB * 2];
+    const int r = threadIdx.x;
+    const int s0 = blockIdx.x * HNB;
+    const int nb = (nbig - s0 < HNB) ? nbig - s0 : HNB;
+    for (int e = r; e < HNB * HNB * E; e += 64) t[e] = 0.0;
+    __syncthreads();
+    for (int i = 0; i < nb; ++i) {
+        const double tr = tau[(s0 + i) * E], ti = CPLX ? tau[(s0 + i) * E + 1] : 0.0;
+        if (r < i) {
+            const double* gp = G + ((long)(s0 + i) * ldg + s0 + r) * E;
+            g[r * E] = gp[0];
+            if (CPLX) g[r * E + 1] = gp[1];
+        }
+        __syncthreads();
+        if (r < i) {                                   // row r of upper-triangular T[0:i,0:i] times g
+            double sr = 0.0, si = 0.0;
+            for (int l = r; l < i; ++l) {
+                const double ar = t[(l * HNB + r) * E], ai = CPLX ? t[(l * HNB + r) * E + 1] : 0.0;
+                const double br = g[l * E], bi = CPLX ? g[l * E + 1] : 0.0;
+                sr += ar * br - ai * bi;
+                si += ar * bi + ai * br;
+            }
+            t[(i * HNB + r) * E] = -(tr * sr - ti * si);
+            if (CPLX) t[(i * HNB + r) * E + 1] = -(tr * si + ti * sr);
+        }
+        if (r == i) { t[(i * HNB + i) * E] = tr; if (CPLX) t[(i * HNB + i) * E + 1] = ti; }
+        __syncthreads();
+    }
+    for (int e = r; e < nb * HNB * E; e += 64) {
+        const int col = e / (HNB * E), rem = e % (HNB * E), row = rem / E, c = rem % E;
+        if (row < nb) T[((long)(s0 + col) * ldt + s0 + row) * E + c] = t[(col * HNB + row) * E + c];
+    }
+}
+
 // Cm (m x ncols, ldc) <- Q * Cm with Q = H_0 H_1 ... H_{nref-1}, reflectors in QR storage (unit at (k,k), tail below) in
-// Vstore (m rows, ldv), scalars tau on the device.  Blocked compact-WY, backward over panels (LAPACK xUNMQR 'L','N').
+// Vstore (m rows, ldv), scalars tau on the device.  Blocked compact-WY, backward over blocks (LAPACK xUNMQR 'L','N').
+// Round 4: the reflectors are aggregated into blocks of ANB = 256 (round 3: 32) so that the three products of a block -
+// V^H C, T (V^H C), C -= V (..) - run with an inner dimension of 256 instead of 32 (the MFMA GEMM spends a launch of K = 32 in
+// its prologue and epilogue); the block's T is assembled from the 32-wide diagonal blocks (larft_diag_kernel) by the
+// recurrence T(0:j, J) = -T(0:j, 0:j) G(0:j, J) T(J, J), two small products per sub-block.  n = 2560 complex: 20.3 -> see
+// profiles/r04_heevd.txt.  CHASE_HIP_APPLYQ_BLOCK overrides the block size (a multiple of 32).
 int hh_apply_q_left(chase_hip_ctx* c, bool cplx, const double* Vstore, long ldv, int m, int nref, const double* tau,
                     double* Cm, long ldc, int ncols)
 {
     if (m <= 0 || nref <= 0 || ncols <= 0) return 0;
     const int E = cplx ? 2 : 1;
     hipStream_t st = c->stream;
-    const int npan = (nref + HNB - 1) / HNB;
-    const size_t szV = (size_t)m * HNB * E, szW = (size_t)HNB * ncols * E, szG = (size_t)HNB * HNB * E;
-    double* blk = nullptr;
-    if (hipMalloc((void**)&blk, (szV + 2 * szW + 2 * szG) * sizeof(double)) != hipSuccess)
-        return set_error(CHASE_HIP_ENOMEM, "apply_q: scratch allocation failed");
-    double* Vb = blk; double* W1 = Vb + szV; double* W2 = W1 + szW; double* G = W2 + szW; double* T = G + szG;
+    static const int anb_env = [] { const char* e = getenv("CHASE_HIP_APPLYQ_BLOCK"); return e ? atoi(e) : 256; }();
+    const int ANB = (anb_env < HNB) ? HNB : (anb_env / HNB) * HNB;
+    const int npan = (nref + ANB - 1) / ANB;
+    const size_t szV = (size_t)m * ANB * E, szW = (size_t)ANB * ncols * E, szG = (size_t)ANB * ANB * E, szY = (size_t)ANB * HNB * E;
+    int rcb = c->ensure_buf(chase_hip_ctx::BUF_APPLYQ, (szV + 2 * szW + 2 * szG + szY) * sizeof(double));
+    if (rcb) return rcb;
+    double* blk = (double*)c->bufs[chase_hip_ctx::BUF_APPLYQ];
+    double* Vb = blk; double* W1 = Vb + szV; double* W2 = W1 + szW; double* G = W2 + szW; double* T = G + szG; double* Y = T + szG;
     auto body = [&]() -> int {
         for (int p = npan - 1; p >= 0; --p) {
-            const int j0 = p * HNB, nb = (nref - j0 < HNB) ? nref - j0 : HNB;
+            const int j0 = p * ANB, nb = (nref - j0 < ANB) ? nref - j0 : ANB;
             const int rows = m - j0;
             unsigned gx = (unsigned)((rows + 1023) / 1024); if (gx > 64) gx = 64; if (gx < 1) gx = 1;
             KL(hipLaunchKernelGGL(extract_v_kernel, dim3(gx, nb), dim3(256), 0, st, Vstore, ldv, m, j0, nb, E, Vb));
             RC(g3(c, cplx, 'C', nb, nb, rows, 1.0, Vb, rows, Vb, rows, 0.0, G, nb));
-            if (cplx) KL(hipLaunchKernelGGL(larft_kernel<true>, dim3(1), dim3(64), 0, st, G, nb, tau + (size_t)j0 * E, T));
-            else      KL(hipLaunchKernelGGL(larft_kernel<false>, dim3(1), dim3(64), 0, st, G, nb, tau + (size_t)j0 * E, T));
+            if (hipMemsetAsync(T, 0, (size_t)nb * nb * E * sizeof(double), st) != hipSuccess) return (int)hipGetLastError();
+            const int nsub = (nb + HNB - 1) / HNB;
+            if (cplx) KL(hipLaunchKernelGGL(larft_diag_kernel<true>, dim3(nsub), dim3(64), 0, st, G, nb, nb, tau + (size_t)j0 * E, T, nb));
+            else      KL(hipLaunchKernelGGL(larft_diag_kernel<false>, dim3(nsub), dim3(64), 0, st, G, nb, nb, tau + (size_t)j0 * E, T, nb));
+            for (int sb = 1; sb < nsub; ++sb) {
+                const int s0 = sb * HNB, w = (nb - s0 < HNB) ? nb - s0 : HNB;
+                // Y = T(0:s0, 0:s0) G(0:s0, s0:s0+w);  T(0:s0, s0:s0+w) = -Y T(s0:s0+w, s0:s0+w)
+                RC(g3(c, cplx, 'N', s0, w, s0, 1.0, T, nb, G + (size_t)s0 * nb * E, nb, 0.0, Y, s0));
+                RC(g3(c, cplx, 'N', s0, w, w, -1.0, Y, s0, T + ((size_t)s0 * nb + s0) * E, nb, 0.0, T + (size_t)s0 * nb * E, nb));
+            }
             double* Cs = Cm + (size_t)j0 * E;
             RC(g3(c, cplx, 'C', nb, ncols, rows, 1.0, Vb, rows, Cs, ldc, 0.0, W1, nb));
-            RC(g3(c, cplx, 'N', nb, ncols, nb, 1.0, T, HNB, W1, nb, 0.0, W2, nb));
+            RC(g3(c, cplx, 'N', nb, ncols, nb, 1.0, T, nb, W1, nb, 0.0, W2, nb));
             RC(g3(c, cplx, 'N', rows, ncols, nb, -1.0, Vb, rows, W2, nb, 1.0, Cs, ldc));
         }
         return 0;
     };
     const int rc = body();
     hipStreamSynchronize(st);
-    hipFree(blk);
     return rc;
 }
 } // namespace chase_hip
