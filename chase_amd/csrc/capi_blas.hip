@@ -365,7 +365,13 @@ int chase_hip_potrf_upper(chase_hip_ctx* c, int cplx, int n, void* A_, long lda)
     return info;
 }
 
-/* V (m x n) <- V R^{-1}, R upper triangular n x n (device).  Blocked: diagonal-block inverses + MFMA GEMM sweeps. */
+/* V (m x n) <- V R^{-1}, R upper triangular n x n (device).  Blocked: diagonal-block inverses + MFMA GEMM sweeps.
+ * Round 4: LEFT-looking over column blocks - block J first receives the contribution of all finished columns in ONE product
+ * with a long inner dimension, V_J -= X(:, 0:J0) R(0:J0, J), then X_J = V_J R_JJ^{-1} (blocks wider than 64: 64-column steps
+ * with rank-64 updates inside the block).  Round 3 was right-looking: each of the 40 steps read and wrote ALL remaining columns
+ * of V with an inner dimension of 64 (107 GB of traffic at config 4: 41.6 ms); left-looking moves 13 GB: 26.5 ms with blocks
+ * of 64 (one column tile per row panel = one round of the chip), 26.8 / 27.7 / 29.5 ms with 128 / 256 / 512
+ * (CHASE_HIP_TRSM_BLOCK, a multiple of 64). */
 int chase_hip_trsm_right_upper(chase_hip_ctx* c, int cplx, int m, int n, const void* R_, long ldr, void* V_, long ldv)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "trsm: NULL ctx");
@@ -381,18 +387,26 @@ int chase_hip_trsm_right_upper(chase_hip_ctx* c, int cplx, int m, int n, const v
     double* Tinv = (double*)c->bufs[chase_hip_ctx::BUF_TINV];
     double* P = (double*)c->bufs[chase_hip_ctx::BUF_PANEL];
     KCHK(trtri_diag(c->stream, cplx != 0, R, ldr, n, Tinv), "trtri_diag");
-    for (int b = 0; b < nblk; ++b) {
-        const int j0 = b * NB;
-        const int nb = (n - j0 < NB) ? n - j0 : NB;
-        double* Vj = V + (long)j0 * ldv * e;
-        // X_j = V_j * T_j      (V_j already carries the updates of the previous block columns)
-        RCCHK(gemm(c, cplx, 'N', m, nb, nb, 1.0, 0.0, Vj, ldv, Tinv + (long)b * NB * NB * e, NB, 0.0, 0.0, P, m));
-        KCHK(copy2d(c->stream, P, (long)m * e, Vj, ldv * e, (long)m * e, nb), "trsm panel copy");
-        const int rest = n - j0 - nb;
-        if (rest > 0) {
-            const double* Rjr = R + ((long)(j0 + nb) * ldr + j0) * e;
-            double* Vr = V + (long)(j0 + nb) * ldv * e;
-            RCCHK(gemm(c, cplx, 'N', m, rest, nb, -1.0, 0.0, P, m, Rjr, ldr, 1.0, 0.0, Vr, ldv));
+    static const int wb_env = [] { const char* s = getenv("CHASE_HIP_TRSM_BLOCK"); return s ? atoi(s) : 64; }();
+    const int WB = (wb_env < NB) ? NB : (wb_env / NB) * NB;
+    for (int J0 = 0; J0 < n; J0 += WB) {
+        const int wb = (n - J0 < WB) ? n - J0 : WB, Jend = J0 + wb;
+        // everything the finished columns contribute to this block, in one product
+        if (J0 > 0)
+            RCCHK(gemm(c, cplx, 'N', m, wb, J0, -1.0, 0.0, V, ldv, R + (long)J0 * ldr * e, ldr, 1.0, 0.0, V + (long)J0 * ldv * e, ldv));
+        for (int j0 = J0; j0 < Jend; j0 += NB) {
+            const int b = j0 / NB;
+            const int nb = (Jend - j0 < NB) ? Jend - j0 : NB;
+            double* Vj = V + (long)j0 * ldv * e;
+            // X_j = V_j * T_j      (V_j already carries the updates of the previous columns)
+            RCCHK(gemm(c, cplx, 'N', m, nb, nb, 1.0, 0.0, Vj, ldv, Tinv + (long)b * NB * NB * e, NB, 0.0, 0.0, P, m));
+            KCHK(copy2d(c->stream, P, (long)m * e, Vj, ldv * e, (long)m * e, nb), "trsm panel copy");
+            const int rest = Jend - j0 - nb;                   // the block's remaining columns only
+            if (rest > 0) {
+                const double* Rjr = R + ((long)(j0 + nb) * ldr + j0) * e;
+                double* Vr = V + (long)(j0 + nb) * ldv * e;
+                RCCHK(gemm(c, cplx, 'N', m, rest, nb, -1.0, 0.0, P, m, Rjr, ldr, 1.0, 0.0, Vr, ldv));
+            }
         }
     }
     return 0;
