@@ -76,16 +76,20 @@ struct SlotTable {
     std::thread::id owner{};
     bool claimed = false;
     std::map<std::thread::id, std::unique_ptr<DistSlot>> extra;
-    DistSlot& for_init()
+    DistSlot& for_init();
+    // the calling thread ends (thread_local guard below): its own slot goes with it - thread ids are reused, and a stale
+    // entry would capture the init of whichever later thread happens to get the same id
+    void drop_thread()
     {
-        std::lock_guard<std::mutex> lk(mu);
-        const auto me = std::this_thread::get_id();
-        auto it = extra.find(me);
-        if (it != extra.end()) return *it->second;
-        if (!claimed || owner == me) { claimed = true; owner = me; return global; }
-        auto& up = extra[me];
-        up.reset(new DistSlot());
-        return *up;
+        std::unique_ptr<DistSlot> mine;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = extra.find(std::this_thread::get_id());
+            if (it == extra.end()) return;
+            mine = std::move(it->second);
+            extra.erase(it);
+        }
+        mine->clear();
     }
     DistSlot& current()
     {
@@ -106,6 +110,20 @@ struct SlotTable {
     }
 };
 SlotTable g_td, g_tz;
+struct ThreadSlotGuard { ~ThreadSlotGuard() { g_td.drop_thread(); g_tz.drop_thread(); } };
+thread_local ThreadSlotGuard g_thread_slot_guard;
+DistSlot& SlotTable::for_init()
+{
+    std::lock_guard<std::mutex> lk(mu);
+    const auto me = std::this_thread::get_id();
+    auto it = extra.find(me);
+    if (it != extra.end()) return *it->second;
+    if (!claimed || owner == me) { claimed = true; owner = me; return global; }
+    (void)&g_thread_slot_guard;                     // constructs this thread's guard: its destructor runs when the thread ends
+    auto& up = extra[me];
+    up.reset(new DistSlot());
+    return *up;
+}
 #define g_pd (g_td.current())
 #define g_pz (g_tz.current())
 thread_local chase_hip_ctx* g_next_ctx = nullptr;           // set by chase_hip_cshim_use_ctx for the next init ON THIS THREAD
