@@ -89,6 +89,20 @@ def test_multi_rank_bench_with_real_rccl_collectives(ngpus, grid):
     assert d["comm_probe"]["col_group_panel_allreduce"]["ranks"] == 2
 
 
+def test_config3_at_full_size_over_real_rccl_communicators():
+    """BASELINE configs[2] exactly as the 4-GPU job runs it (N = 32768 real symmetric, nev = 1024, nex = 256, 2 x 2 block
+    distribution, RCCL row / column all-reduces) - with the four rank processes sharing this box's one GPU and RCCL on its socket
+    transport (one NCCL_HOSTID per rank): same iteration and filtered-vector counts as the host-fabric run of
+    tests/test_gpu_fullsize.py, analytic spectrum, independent residuals."""
+    d = run_bench("--gpus", "4", "--workload", "cfg3", "--steps", "9", "--warmup", "0", "--no-cpu-baseline", "--no-probe",
+                  env={"CHASE_BENCH_FAKE_HOSTS": "1"})
+    assert d["n_gpus"] == 4 and d["config"]["grid"] == "2x2" and d["config"]["transport"] == "rccl" and d["dtype"] == "f64"
+    assert d["ranks_seen_by_rccl"]["grid"] == 4
+    assert d["iterations_per_solve"] == 9 and abs(d["filtered_vecs_per_solve"] - 207784) <= 0.005 * 207784
+    assert d["converged"] is True and d["spectrum_check"]["ok"] is True and d["max_resid_recomputed"] < 1e-8
+    assert d["comm_waits"] > 0
+
+
 def test_launcher_ranks_settle_their_mode_with_real_probe_children():
     """the driver's multi-GPU call (`torch.distributed.run ... bench.py --gpus 2`) with `--ranks auto` and REAL RCCL (fake hosts):
     every rank starts its own probe child, the children build real communicators on their own port, run the 256 MB proof and
