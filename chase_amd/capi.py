@@ -248,6 +248,7 @@ _sig("chase_hip_scale_rows_bc", c_int, c_void_p, c_int, c_int, c_int, c_void_p, 
 _sig("chase_hip_conj", c_int, c_void_p, c_int, c_int, c_void_p, c_long)
 _sig("chase_hip_resid_norms", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p,
      c_void_p, c_int)
+_sig("chase_hip_gemm_workspace_bytes", c_size_t, c_int, C.c_char, c_int, c_int, c_int, c_int, c_int)
 _sig("chase_hip_herk", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long)
 _sig("chase_hip_herkx", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int)
 _sig("chase_hip_abs_trace", c_int, c_void_p, c_int, c_int, c_void_p, c_long, P(c_double))

@@ -229,6 +229,12 @@ int chase_hip_gemm_z(chase_hip_ctx* c, char opA, int m, int n, int k, const doub
     return c->gemm(true, opA, m, n, k, alpha, (const double*)A, lda, (const double*)B, ldb, beta, (double*)C, ldc);
 }
 
+/* bytes of split-K workspace chase_hip_gemm_{d,z} uses for this shape on a device with num_cu compute units (a pure function
+ * of the shape: the launcher never picks another split to fit what happens to be allocated) */
+size_t chase_hip_gemm_workspace_bytes(int cplx, char opA, int m, int n, int k, int num_cu, int min_rounds)
+{
+    return gemm_f64_ws_need(cplx != 0, opA, m, n, k, num_cu, min_rounds);
+}
 int chase_hip_gemm3m_enabled(void) { return gemm3m_enabled(); }
 int chase_hip_set_gemm3m(int on)
 {

@@ -76,6 +76,10 @@ int chase_hip_gemm_z(chase_hip_ctx* ctx, char opA, int m, int n, int k, const do
  * reference's zgemm).  It applies to launches with m a multiple of 128, k a multiple of 8 and 16-byte addressable
  * operands; other shapes, and every other product (Gram matrices, back-transforms, QR, phase 3), take the
  * four-multiplication kernel. */
+/* bytes of split-K workspace a product of this shape uses on a device with num_cu compute units (context-owned, grown on
+ * demand; min_rounds as in chase_hip_ctx_set_gemm_min_rounds) - a pure function of the shape, so that the decomposition and
+ * with it the summation order never depend on allocation history.  Host-only: callable without a GPU. */
+size_t chase_hip_gemm_workspace_bytes(int cplx, char opA, int m, int n, int k, int num_cu, int min_rounds);
 int chase_hip_gemm3m_enabled(void);
 int chase_hip_set_gemm3m(int on); /* process-wide run-time switch */
 /* GEMM books of a context, per phase (0 other, 1 filter, 2 H-times-block outside the filter, 3 verification): flops in the reference's

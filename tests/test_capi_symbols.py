@@ -54,3 +54,23 @@ def test_fails_loudly_without_gpu_or_runs_on_one():
 def test_host_lapack_provider_is_bound():
     from chase_amd import capi
     assert capi.lib.chase_hip_lapack_provider() != b""
+
+
+def test_gemm_workspace_covers_the_rims_of_a_split_three_multiplication_product():
+    """A complex filter product of arbitrary size is cut into a 3M bulk (whole 128-row and 8-deep tiles) and two thin 4M rims
+    (gemm_mfma_f64.hip launch_gemm); the launcher REFUSES a workspace smaller than a piece's plan (it never re-plans to fit), so
+    the size the context allocates for the whole shape must cover every piece.  Host-only function: no GPU needed."""
+    from chase_amd.capi import lib
+    need = lambda op, m, n, k, r=0: lib.chase_hip_gemm_workspace_bytes(1, op, m, n, k, 256, r)
+    for op in (b"N", b"C"):
+        for (m, n, k) in [(1001, 160, 1001), (8193, 640, 16384), (16384, 133, 8190), (65536, 2560, 65536), (1200, 140, 1200)]:
+            m1, k1 = m - m % 128, k - k % 8
+            whole = need(op, m, n, k)
+            pieces = [need(op, m1, n, k1)]
+            if k1 < k:
+                pieces.append(need(op, m1, n, k - k1))
+            if m1 < m:
+                pieces.append(need(op, m - m1, n, k))
+            assert whole >= max(pieces), (op, m, n, k, whole, pieces)
+            assert need(op, m, n, k, 4) >= whole or need(op, m, n, k, 4) > 0       # shared-chip granularity: its own plan
+    assert need(b"N", 0, 5, 5) == 0
