@@ -712,6 +712,13 @@ def main():
                     help="how the ranks of a multi-GPU run hold their devices: processes (= bound: one process per GPU, one "
                          "visible device each), unbound (all devices visible), threads (one process, one thread per GPU), "
                          "auto (default): the first of bound / unbound / threads whose transport probe passes")
+    ap.add_argument("--replay-rank", default=None, metavar="GRIDS",
+                    help="single-rank replay (chase_amd/replay.py): e.g. 4x2 or 4x2,2x2,2x1 - ONE rank of each grid is driven "
+                         "through the taped call sequence of a real single-GPU solve of the workload on a loopback grid (no "
+                         "communication): the compute side of the multi-GPU solve, measured on one GPU")
+    ap.add_argument("--tape", default=None, help="scalar tape file (.npz): loaded if it exists, else recorded and saved there")
+    ap.add_argument("--replay-rank-index", type=int, default=0, help="which rank of the grid is replayed (default 0 = (0,0))")
+    ap.add_argument("--oplog-out", default=None, help="write the replayed rank's operator log there (%%g = grid)")
     ap.add_argument("--transport-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -758,6 +765,10 @@ def main():
         if out is not None:
             os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
+    if args.replay_rank:
+        from chase_amd.replay import run as run_replay
+        emit(run_replay(args))
+        return
     if mode == "threads" and (args.gpus > 1 or world > 1):
         from chase_amd.dist_bench import run_threads
         emit(run_threads(args, max(args.gpus, world)))

@@ -50,6 +50,8 @@ _sig("chase_hip_ctx_create", c_int, P(c_void_p), c_int, c_void_p)
 _sig("chase_hip_ctx_destroy", c_int, c_void_p)
 _sig("chase_hip_ctx_sync", c_int, c_void_p)
 _sig("chase_hip_ctx_stream", c_void_p, c_void_p)
+_sig("chase_hip_ctx_oplog", c_int, c_void_p, c_int)
+_sig("chase_hip_ctx_oplog_text", C.c_char_p, c_void_p)
 _sig("chase_hip_device_info", c_int, c_void_p, P(c_int), P(c_int), P(c_size_t), C.c_char_p, c_int)
 _sig("chase_hip_device_bus_id", c_int, c_void_p, C.c_char_p, c_int)
 _sig("chase_hip_device_count", c_int)
@@ -143,6 +145,13 @@ class Context:
 
     def sync(self):
         check(lib.chase_hip_ctx_sync(self.h), "ctx_sync")
+
+    def oplog(self, on):
+        """Start (fresh) / stop the operator log of this context (chase_hip_ctx_oplog)."""
+        check(lib.chase_hip_ctx_oplog(self.h, int(on)), "ctx_oplog")
+
+    def oplog_lines(self):
+        return lib.chase_hip_ctx_oplog_text(self.h).decode().splitlines()
 
     def info(self):
         ncu, clk, mem = c_int(), c_int(), c_size_t()
@@ -295,6 +304,11 @@ _sig("chase_hip_solver_stats", c_int, c_void_p, P(Stats))
 _sig("chase_hip_solver_resid", P(c_double), c_void_p)
 _sig("chase_hip_solver_trace", C.c_char_p, c_void_p)
 _sig("chase_hip_solver_recompute_residuals", c_int, c_void_p, c_size_t, c_void_p, c_void_p)
+_sig("chase_hip_solver_tape_mode", c_int, c_void_p, c_int)
+_sig("chase_hip_solver_tape_data", c_int, c_void_p, P(P(c_double)), P(c_size_t))
+_sig("chase_hip_solver_tape_load", c_int, c_void_p, c_void_p, c_size_t)
+_sig("chase_hip_resid_norms_dev", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p,
+     c_void_p, c_int)
 _sig("chase_hip_solver_peek_v", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
 _sig("chase_hip_op_start", c_int, c_void_p)
 _sig("chase_hip_op_end", c_int, c_void_p)
@@ -333,6 +347,26 @@ def recompute_residuals(solver, ncols, lam=None):
     out = np.zeros(ncols)
     check(lib.chase_hip_solver_recompute_residuals(solver.h, ncols, lam.ctypes.data, out.ctypes.data), "recompute_residuals")
     return out
+
+
+TAPE_OFF, TAPE_RECORD, TAPE_REPLAY = 0, 1, 2
+
+
+def tape_mode(solver, mode):
+    """0 off, 1: the next solves record everything the Impl tells the driver, 2: they replay the loaded tape (tape.hpp)."""
+    check(lib.chase_hip_solver_tape_mode(solver.h, int(mode)), "tape_mode")
+
+
+def tape_get(solver):
+    """The scalar tape of the last recorded solve as a float64 array (frames: tag, count, values...)."""
+    p, n = P(c_double)(), c_size_t()
+    check(lib.chase_hip_solver_tape_data(solver.h, C.byref(p), C.byref(n)), "tape_data")
+    return np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0)
+
+
+def tape_load(solver, tape):
+    t = np.ascontiguousarray(tape, dtype=np.float64)
+    check(lib.chase_hip_solver_tape_load(solver.h, t.ctypes.data, t.size), "tape_load")
 
 
 def gemm_counters(ctx, phase, reset=False):

@@ -107,6 +107,7 @@ int chase_hip_fill_normal(chase_hip_ctx* c, int cplx, int m, int n, void* X, lon
 {
     if (!c || !X) return set_error(CHASE_HIP_EINVAL, "fill_normal: NULL argument");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("fill_normal", m, n, 0, 0);
     if (m < 0 || n < 0 || ldx < m) return set_error(CHASE_HIP_EINVAL, "fill_normal: bad shape");
     KCHK(fill_normal(c->stream, cplx != 0, (double*)X, ldx, m, n, grow0, gcol0, gld, seed), "fill_normal");
     return 0;
@@ -118,6 +119,7 @@ int chase_hip_fill_normal_bc(chase_hip_ctx* c, int cplx, int m, int n, void* X, 
 {
     if (!c || !X) return set_error(CHASE_HIP_EINVAL, "fill_normal_bc: NULL argument");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("fill_normal_bc", m, n, 0, 0);
     if (m < 0 || n < 0 || ldx < m || mb <= 0 || pr <= 0) return set_error(CHASE_HIP_EINVAL, "fill_normal_bc: bad shape");
     KCHK(fill_normal(c->stream, cplx != 0, (double*)X, ldx, m, n, 0, 0, gld, seed, mb, pr, pi), "fill_normal_bc");
     return 0;
@@ -129,6 +131,7 @@ int chase_hip_rows_indexed(chase_hip_ctx* c, int cplx, const void* in, long ld_i
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "rows_indexed: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("rows_indexed", np, ncols, scatter, 0);
     KCHK(rows_indexed(c->stream, cplx != 0, (const double*)in, ld_in, (double*)out, ld_out, idx_dev, np, ncols, scatter),
          "rows_indexed");
     return 0;
@@ -167,6 +170,7 @@ int chase_hip_shift_diag(chase_hip_ctx* c, int cplx, int n, void* H, long ldh, d
 {
     if (!c || (!H && n > 0)) return set_error(CHASE_HIP_EINVAL, "shift_diag: NULL argument");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("shift_diag", n, 0, 0, 0);
     if (n < 0 || ldh < n) return set_error(CHASE_HIP_EINVAL, "shift_diag: bad shape");
     KCHK(shift_diag(c->stream, (double*)H, ldh, n, ept_of(cplx), shift), "shift_diag");
     return 0;
@@ -177,6 +181,7 @@ int chase_hip_shift_list(chase_hip_ctx* c, int cplx, void* H, long ldh, const in
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "shift_list: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("shift_list", cnt, 0, 0, 0);
     if (cnt < 0) return set_error(CHASE_HIP_EINVAL, "shift_list: negative count");
     KCHK(shift_list(c->stream, (double*)H, ldh, rows_dev, cols_dev, cnt, ept_of(cplx), shift), "shift_list");
     return 0;
@@ -186,6 +191,7 @@ int chase_hip_lacpy(chase_hip_ctx* c, int cplx, int m, int n, const void* A, lon
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "lacpy: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("lacpy", m, n, 0, 0);
     if (m < 0 || n < 0 || lda < m || ldb < m) return set_error(CHASE_HIP_EINVAL, "lacpy: bad shape");
     if (m == 0 || n == 0) return 0;
     const int e = ept_of(cplx);
@@ -197,6 +203,7 @@ int chase_hip_swap_cols(chase_hip_ctx* c, int cplx, int m, void* V, long ldv, lo
 {
     if (!c || !V) return set_error(CHASE_HIP_EINVAL, "swap_cols: NULL argument");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("swap_cols", m, 0, 0, 0);
     if (i == j) return 0;
     const int e = ept_of(cplx);
     double* v = (double*)V;
@@ -211,6 +218,7 @@ int chase_hip_permute_cols(chase_hip_ctx* c, int cplx, int m, void* V, long ldv,
 {
     if (!c || !V || !scratch) return set_error(CHASE_HIP_EINVAL, "permute_cols: NULL argument");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("permute_cols", m, cnt, 0, 0);
     if (cnt <= 0) return 0;
     const int e = ept_of(cplx);
     RCCHK(c->ensure_buf(chase_hip_ctx::BUF_LAMBDA, (size_t)2 * cnt * sizeof(int) + 64));
@@ -232,6 +240,7 @@ int chase_hip_upload_matrix(chase_hip_ctx* c, int cplx, int m, int n, const void
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "upload_matrix: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("upload_matrix", m, n, 0, 0);
     if (m <= 0 || n <= 0) return 0;
     const size_t es = sizeof(double) * ept_of(cplx);
     HIPCHK(hipMemcpy2DAsync(dev, (size_t)ldd * es, host, (size_t)ldh * es, (size_t)m * es, n, hipMemcpyHostToDevice,
@@ -243,6 +252,7 @@ int chase_hip_download_matrix(chase_hip_ctx* c, int cplx, int m, int n, const vo
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "download_matrix: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("download_matrix", m, n, 0, 0);
     if (m <= 0 || n <= 0) return 0;
     const size_t es = sizeof(double) * ept_of(cplx);
     HIPCHK(hipMemcpy2DAsync(host, (size_t)ldh * es, dev, (size_t)ldd * es, (size_t)m * es, n, hipMemcpyDeviceToHost,
@@ -255,6 +265,7 @@ int chase_hip_scale_rows(chase_hip_ctx* c, int cplx, int m, int n, void* X, long
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "scale_rows: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("scale_rows", m, n, row0, 0);
     const int e = ept_of(cplx);
     KCHK(scale_rows(c->stream, (double*)X, ldx * e, (long)row0 * e, (long)m * e, n, s), "scale_rows");
     return 0;
@@ -265,6 +276,7 @@ int chase_hip_scale_rows_bc(chase_hip_ctx* c, int cplx, int m, int n, void* X, l
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "scale_rows_bc: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("scale_rows_bc", m, n, 0, 0);
     if (nb <= 0 || p <= 0 || q < 0 || q >= p || (n > 0 && ldx < m)) return set_error(CHASE_HIP_EINVAL, "scale_rows_bc: bad layout");
     const int e = ept_of(cplx);
     KCHK(scale_rows_bc(c->stream, (double*)X, ldx * e, (long)m, n, e, g0, nb, p, q, s), "scale_rows_bc");
@@ -275,6 +287,7 @@ int chase_hip_conj(chase_hip_ctx* c, int m, int n, void* X, long ldx)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "conj: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("conj", m, n, 0, 0);
     KCHK(conj_inplace(c->stream, (double*)X, ldx * 2, m, n), "conj");
     return 0;
 }
@@ -290,6 +303,7 @@ int chase_hip_herkx(chase_hip_ctx* c, int cplx, int n, int k, const void* A_, lo
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "herkx: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("herkx", n, k, mirror, 0);
     if (n < 0 || k < 0 || lda < k || ldb < k || ldc < n) return set_error(CHASE_HIP_EINVAL, "herkx: bad shape");   // k = 0: C = 0
     if (n == 0) return 0;
     const int e = ept_of(cplx);
@@ -319,6 +333,7 @@ int chase_hip_abs_trace(chase_hip_ctx* c, int cplx, int n, const void* A, long l
 {
     if (!c || !out_host) return set_error(CHASE_HIP_EINVAL, "abs_trace: NULL argument");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("abs_trace", n, 0, 0, 0);
     RCCHK(c->ensure_buf(chase_hip_ctx::BUF_SCAL, 4096));
     double* d = (double*)c->bufs[chase_hip_ctx::BUF_SCAL];
     KCHK(abs_trace(c->stream, (const double*)A, lda, n, ept_of(cplx), d), "abs_trace");
@@ -333,6 +348,7 @@ int chase_hip_potrf_upper(chase_hip_ctx* c, int cplx, int n, void* A_, long lda)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "potrf: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("potrf_upper", n, 0, 0, 0);
     if (n < 0 || lda < n) return set_error(CHASE_HIP_EINVAL, "potrf: bad shape");
     if (n == 0) return 0;
     const int e = ept_of(cplx);
@@ -376,6 +392,7 @@ int chase_hip_trsm_right_upper(chase_hip_ctx* c, int cplx, int m, int n, const v
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "trsm: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("trsm_right_upper", m, n, 0, 0);
     if (m < 0 || n < 0 || ldr < n || ldv < m) return set_error(CHASE_HIP_EINVAL, "trsm: bad shape");
     if (m == 0 || n == 0) return 0;
     const int e = ept_of(cplx);
@@ -421,6 +438,7 @@ int chase_hip_cholqr(chase_hip_ctx* c, int cplx, int m, int n, void* V, long ldv
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "cholqr: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("cholqr", m, n, variant, 0);
     if (variant < 1 || variant > 3) return set_error(CHASE_HIP_EINVAL, "cholqr: variant must be 1, 2 or 3");
     if (n == 0 || m == 0) return 0;
     int info;
@@ -451,6 +469,7 @@ int chase_hip_resid_norms(chase_hip_ctx* c, int cplx, int m, int n, const void* 
 {
     if (!c || !resid_host || (V && !lambda_host)) return set_error(CHASE_HIP_EINVAL, "resid_norms: NULL argument");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("resid_norms", m, n, squared, 0);
     if (n <= 0) return 0;
     const int e = ept_of(cplx);
     RCCHK(c->ensure_buf(chase_hip_ctx::BUF_LAMBDA, (size_t)2 * n * sizeof(double)));
@@ -464,6 +483,25 @@ int chase_hip_resid_norms(chase_hip_ctx* c, int cplx, int m, int n, const void* 
     return 0;
 }
 
+/* the same with the result left in DEVICE memory (out_dev: n doubles): the distributed Impl sums the squares over the row
+ * group on the device and reads them back once (linalg/internal/nccl/residuals.hpp:28-88 keeps them on the device as well) */
+int chase_hip_resid_norms_dev(chase_hip_ctx* c, int cplx, int m, int n, const void* W, long ldw, const void* V, long ldv,
+                              const double* lambda_host, double* out_dev, int squared)
+{
+    if (!c || !out_dev || (V && !lambda_host)) return set_error(CHASE_HIP_EINVAL, "resid_norms_dev: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("resid_norms_dev", m, n, squared, 0);
+    if (n <= 0) return 0;
+    const int e = ept_of(cplx);
+    RCCHK(c->ensure_buf(chase_hip_ctx::BUF_LAMBDA, (size_t)2 * n * sizeof(double)));
+    double* dl = (double*)c->bufs[chase_hip_ctx::BUF_LAMBDA];
+    // lambda_host is pageable host memory: the copy is staged by the runtime before the call returns
+    if (V) HIPCHK(hipMemcpyAsync(dl, lambda_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    KCHK(resid_norms(c->stream, (const double*)W, ldw * e, (const double*)V, ldv * e, dl, (long)m * e, n, out_dev,
+                     squared ? 0 : 1), "resid_norms");
+    return 0;
+}
+
 /* Hermitian eigendecomposition of the device matrix A (n x n, lower triangle referenced) on the HOST
  * (north star: "small HEEV on host"; reference lapackpp::t_heevd 'V','L').  Eigenvalues ascending to w_host,
  * eigenvectors overwrite A on the device. */
@@ -473,13 +511,20 @@ int chase_hip_heevd(chase_hip_ctx* c, int cplx, int n, void* A, long lda, double
 {
     if (!c || !w_host) return set_error(CHASE_HIP_EINVAL, "heevd: NULL argument");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("heevd", n, 0, 0, 0);
     if (n < 0 || lda < n) return set_error(CHASE_HIP_EINVAL, "heevd: bad shape");
     if (n == 0) return 0;
     {   // large projected problems: tridiagonalise and back-transform on the GPU, only the O(n^2) tridiagonal solve on
         // the host (hetrd.hip).  CHASE_HIP_HEEVD_GPU_MIN overrides the switch-over size (0 = always host).
         static int thr = -1;
         if (thr < 0) { const char* e = getenv("CHASE_HIP_HEEVD_GPU_MIN"); thr = e ? atoi(e) : 384; }
-        if (thr > 0 && n >= thr) return chase_hip_heevd_gpu(c, cplx, n, A, lda, w_host);
+        if (thr > 0 && n >= thr) {
+            // the divide & conquer stage's launches depend on the data (deflation): the operator log lists heevd only
+            ++c->oplog_mute;
+            const int rc = chase_hip_heevd_gpu(c, cplx, n, A, lda, w_host);
+            --c->oplog_mute;
+            return rc;
+        }
     }
     const int e = ept_of(cplx);
     const size_t colb = (size_t)n * sizeof(double) * e;
@@ -529,6 +574,7 @@ int chase_hip_pseudo_rr_small(chase_hip_ctx* c, int cplx, int n, void* A_dev, vo
 {
     if (!c || !A_dev || !M_dev || !ritzv_host) return set_error(CHASE_HIP_EINVAL, "pseudo_rr_small: NULL argument");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("pseudo_rr_small", n, 0, 0, 0);
     if (n <= 0) return 0;
     const size_t bytes = (size_t)n * n * sizeof(double) * ept_of(cplx);
     RCCHK(c->ensure_hstage(2 * bytes));
@@ -569,6 +615,7 @@ int chase_hip_set_identity(chase_hip_ctx* c, int cplx, int n, void* A, long lda)
 {
     if (!c || !A) return set_error(CHASE_HIP_EINVAL, "set_identity: NULL argument");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("set_identity", n, 0, 0, 0);
     HIPCHK(hipMemset2DAsync(A, (size_t)lda * sizeof(double) * ept_of(cplx), 0, (size_t)n * sizeof(double) * ept_of(cplx), n, c->stream));
     KCHK(shift_diag(c->stream, (double*)A, lda, n, ept_of(cplx), 1.0), "set_identity");
     return 0;
@@ -590,6 +637,7 @@ int chase_hip_stedc(chase_hip_ctx* c, int n, const double* d_host, const double*
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "stedc: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("stedc", n, 0, 0, 0);
     return stedc_gpu(c, n, d_host, e_host, w_host, Z_dev, ldz);
 }
 
@@ -599,6 +647,7 @@ int chase_hip_col_dot(chase_hip_ctx* c, int cplx, int m, int n, const void* X, l
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "col_dot: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("col_dot", m, n, 0, 0);
     const int e = ept_of(cplx);
     KCHK(col_dot(c->stream, cplx != 0, (const double*)X, ldx * e, (const double*)Y, ldy * e, m, n, out_dev), "col_dot");
     return 0;
@@ -607,6 +656,7 @@ int chase_hip_col_nrm2(chase_hip_ctx* c, int cplx, int m, int n, const void* X, 
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "col_nrm2: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("col_nrm2", m, n, 0, 0);
     const int e = ept_of(cplx);
     KCHK(resid_norms(c->stream, (const double*)X, ldx * e, nullptr, 0, nullptr, (long)m * e, n, out_dev, 1), "col_nrm2");
     return 0;
@@ -616,6 +666,7 @@ int chase_hip_col_sumsq(chase_hip_ctx* c, int cplx, int m, int n, const void* X,
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "col_sumsq: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("col_sumsq", m, n, 0, 0);
     const int e = ept_of(cplx);
     KCHK(resid_norms(c->stream, (const double*)X, ldx * e, nullptr, 0, nullptr, (long)m * e, n, out_dev, 0), "col_sumsq");
     return 0;
@@ -624,6 +675,7 @@ int chase_hip_sqrt_inplace(chase_hip_ctx* c, double* x_dev, int n)
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "sqrt_inplace: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("sqrt_inplace", n, 0, 0, 0);
     KCHK(sqrt_inplace(c->stream, x_dev, n), "sqrt_inplace");
     return 0;
 }
@@ -632,6 +684,7 @@ int chase_hip_col_axpy(chase_hip_ctx* c, int cplx, int m, int n, const double* a
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "col_axpy: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("col_axpy", m, n, a_is_real, 0);
     const int e = ept_of(cplx);
     KCHK(col_axpy(c->stream, cplx != 0, a_dev, a_is_real, a_stride, sgn, (const double*)X, ldx * e, (double*)Y, ldy * e,
                   m, n), "col_axpy");
@@ -641,6 +694,7 @@ int chase_hip_col_scal(chase_hip_ctx* c, int cplx, int m, int n, const double* a
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "col_scal: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("col_scal", m, n, inverse, 0);
     const int e = ept_of(cplx);
     KCHK(col_scal(c->stream, a_dev, inverse, (double*)X, ldx * e, (long)m * e, n), "col_scal");
     return 0;
@@ -651,6 +705,7 @@ int chase_hip_pack_upper(chase_hip_ctx* c, int cplx, int n, const void* A, long 
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "pack_upper: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("pack_upper", n, 0, 0, 0);
     KCHK(pack_upper(c->stream, (const double*)A, lda, n, ept_of(cplx), (double*)P), "pack_upper");
     return 0;
 }
@@ -658,6 +713,7 @@ int chase_hip_unpack_upper(chase_hip_ctx* c, int cplx, int n, const void* P, voi
 {
     if (!c) return set_error(CHASE_HIP_EINVAL, "unpack_upper: NULL ctx");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("unpack_upper", n, mirror, 0, 0);
     KCHK(unpack_upper(c->stream, (double*)P, n, ept_of(cplx), (double*)A, lda), "unpack_upper");
     if (mirror) KCHK(mirror_upper(c->stream, (double*)A, lda, n, ept_of(cplx)), "mirror_upper");
     return 0;

@@ -103,6 +103,23 @@ int chase_hip_ctx_sync(chase_hip_ctx* c)
 
 void* chase_hip_ctx_stream(chase_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
+/* operator log: on != 0 starts a fresh log, 0 stops it; the text ('\n'-separated lines "name a b c d") stays readable until
+ * the next call with on != 0 */
+int chase_hip_ctx_oplog(chase_hip_ctx* c, int on)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "ctx == NULL");
+    if (on) { c->oplog.clear(); c->oplog_mute = 0; }
+    c->oplog_on = on != 0;
+    return 0;
+}
+const char* chase_hip_ctx_oplog_text(chase_hip_ctx* c)
+{
+    if (!c) return "";
+    c->oplog_text.clear();
+    for (const auto& l : c->oplog) { c->oplog_text += l; c->oplog_text += '\n'; }
+    return c->oplog_text.c_str();
+}
+
 int chase_hip_device_bus_id(chase_hip_ctx* c, char* out, int len)
 {
     if (!c || !out || len < 16) return set_error(CHASE_HIP_EINVAL, "device_bus_id: bad argument");

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <string>
+#include <vector>
 
 struct chase_hip_ctx {
     int device = 0;
@@ -26,6 +28,16 @@ struct chase_hip_ctx {
     size_t buf_bytes[NBUF] = {};
     void* hstage = nullptr;      // pinned host staging (HEEVD round trip)
     size_t hstage_bytes = 0;
+
+    // operator log (chase_hip_ctx_oplog): one line per C-ABI operator this context executes - name and shapes, no pointers, no
+    // scalars - so that two runs can be compared launch for launch (single-rank replay against the real rank, tests).
+    // oplog_mute > 0: inside an operator whose inner launches depend on the DATA (the divide & conquer eigensolver's
+    // deflation), only the operator itself is listed.
+    bool oplog_on = false;
+    int oplog_mute = 0;
+    std::vector<std::string> oplog;
+    std::string oplog_text;
+    void oplog_add(const char* name, long a, long b, long c, long d);
 
     int ensure_ws(size_t bytes);
     int ensure_buf(int idx, size_t bytes);

@@ -10,16 +10,30 @@ struct chase_hip_grid {
     chase_hip_ctx* ctx = nullptr;
     int nprow = 1, npcol = 1, rank = 0, myrow = 0, mycol = 0;
     bool use_rccl = false;
+    // loopback: a transport for ONE rank of a larger grid with nothing on the other side (single-rank replay of a
+    // multi-GPU solve, bench.py --replay-rank): collectives keep their stream ordering, events and waits exactly as with
+    // RCCL but enqueue no communication (optionally one read+write pass over the payload, loopback_touch: the HBM traffic a
+    // ring all-reduce causes on this device).  Results are wrong by construction; the compute side's time is right.
+    bool loopback = false;
+    bool loopback_touch = false;
     bool force = false;                               // CHASE_HIP_RCCL_FORCE: run size-1 groups through RCCL too (testing)
     ncclComm_t comm[2] = {nullptr, nullptr};          // [ROW], [COL]
-    hipStream_t comm_stream = nullptr;
-    hipEvent_t ev_compute = nullptr, ev_comm = nullptr;
+    // one communication stream per group: on a 4 x 2 grid the row and column communicators use disjoint xGMI links, so
+    // their collectives need not queue behind each other (CHASE_HIP_COMM_STREAMS=1 / chase_hip_grid_set_comm_streams
+    // put both groups on stream 0 - round 4's behaviour)
+    hipStream_t comm_stream[2] = {nullptr, nullptr};
+    int nstreams = 2;
+    bool pending[2] = {false, false};                 // collectives issued on stream i since the compute stream last waited
+    hipEvent_t ev_compute = nullptr, ev_comm[2] = {nullptr, nullptr};
+    hipStream_t stream_of(int group) const { return comm_stream[nstreams == 2 ? group : 0]; }
+    int stream_index(int group) const { return nstreams == 2 ? group : 0; }
+    bool async_transport() const { return use_rccl || loopback; }
     chase_hip_host_allreduce_fn h_allreduce = nullptr;
     chase_hip_host_bcast_fn h_bcast = nullptr;
     chase_hip_host_sendrecv_fn h_sendrecv = nullptr;
     void* h_user = nullptr;
     double* scal_dev = nullptr;                        // one double for agree_max
-    std::vector<hipEvent_t> slots;                     // per-panel 'all-reduce done' events (pipelined HEMM)
+    std::vector<hipEvent_t> slots[2];                  // per-panel 'all-reduce done' events (pipelined HEMM), per stream
     // profiling of exposed communication: every wait of the compute stream on the communication stream is bracketed by
     // two timing events; their distance is the time the compute stream had nothing to do but wait
     bool profiling = false;
@@ -31,5 +45,6 @@ struct chase_hip_grid {
     int collect_exposed();                             // synchronises the compute stream, folds the pending brackets in
     int group_size(int g) const { return g == CHASE_HIP_ROW ? npcol : nprow; }
     bool active(int g) const { return group_size(g) > 1 || (force && use_rccl); }
+    chase_hip_ctx* octx() const { return ctx; }
     int group_rank(int g) const { return g == CHASE_HIP_ROW ? mycol : myrow; }
 };

@@ -26,6 +26,26 @@ using namespace chase_hip;
         }                                                                                                              \
     } while (0)
 
+// one read + write pass over a collective's payload (loopback_touch): what a ring all-reduce costs this device's HBM
+__global__ void loopback_touch_kernel(double* x, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double v = __builtin_nontemporal_load(x + i);
+        __builtin_nontemporal_store(v, x + i);
+    }
+}
+static int loopback_touch_launch(hipStream_t st, double* x, size_t n)
+{
+    if (!n) return 0;
+    // few workgroups, like a collective's kernels (RCCL runs its rings on a handful of CUs)
+    const int blocks = (int)std::min<size_t>(32, (n + 255) / 256);
+    hipLaunchKernelGGL(loopback_touch_kernel, dim3(blocks), dim3(256), 0, st, x, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "loopback_touch_kernel");
+    return 0;
+}
+
 static int grid_common(chase_hip_grid* g, chase_hip_ctx* ctx, int nprow, int npcol, int rank)
 {
     if (!ctx) return set_error(CHASE_HIP_EINVAL, "grid: NULL ctx");
@@ -38,9 +58,12 @@ static int grid_common(chase_hip_grid* g, chase_hip_ctx* ctx, int nprow, int npc
     // the collectives' few workgroups must not queue behind a chip-filling GEMM launch: highest stream priority
     int prio_lo = 0, prio_hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    HIPCHK(hipStreamCreateWithPriority(&g->comm_stream, hipStreamNonBlocking, prio_hi));
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipStreamCreateWithPriority(&g->comm_stream[i], hipStreamNonBlocking, prio_hi));
+        HIPCHK(hipEventCreateWithFlags(&g->ev_comm[i], hipEventDisableTiming));
+    }
     HIPCHK(hipEventCreateWithFlags(&g->ev_compute, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&g->ev_comm, hipEventDisableTiming));
+    if (const char* e = getenv("CHASE_HIP_COMM_STREAMS")) g->nstreams = atoi(e) == 1 ? 1 : 2;
     HIPCHK(hipMalloc((void**)&g->scal_dev, 64));
     return 0;
 }
@@ -119,10 +142,10 @@ int chase_hip_grid_create_rccl(chase_hip_grid** out, chase_hip_ctx* ctx, int npr
         }
         // first collective on a communicator sets up the xGMI connections (hundreds of ms): pay it here, not in the first
         // filter step, and surface transport problems at construction
-        HIPCHK(hipMemsetAsync(g->scal_dev, 0, 64, g->comm_stream));
+        HIPCHK(hipMemsetAsync(g->scal_dev, 0, 64, g->comm_stream[0]));
         for (int grp = 0; grp < 2; ++grp)
-            if (g->comm[grp]) NCCLCHK(ncclAllReduce(g->scal_dev, g->scal_dev, 8, ncclDouble, ncclSum, g->comm[grp], g->comm_stream));
-        HIPCHK(hipStreamSynchronize(g->comm_stream));
+            if (g->comm[grp]) NCCLCHK(ncclAllReduce(g->scal_dev, g->scal_dev, 8, ncclDouble, ncclSum, g->comm[grp], g->comm_stream[0]));
+        HIPCHK(hipStreamSynchronize(g->comm_stream[0]));
         return 0;
     }();
     if (rc) {
@@ -149,24 +172,56 @@ int chase_hip_grid_create_host(chase_hip_grid** out, chase_hip_ctx* ctx, int npr
     return 0;
 }
 
+/* ONE rank of an nprow x npcol grid with nobody on the other side (see grid.h): every collective keeps the stream ordering,
+ * events and waits of the RCCL transport and moves nothing. */
+int chase_hip_grid_create_loopback(chase_hip_grid** out, chase_hip_ctx* ctx, int nprow, int npcol, int rank)
+{
+    if (!out) return set_error(CHASE_HIP_EINVAL, "grid_create: NULL out");
+    chase_hip_grid* g = new chase_hip_grid();
+    int rc = grid_common(g, ctx, nprow, npcol, rank);
+    if (rc) { chase_hip_grid_destroy(g); return rc; }
+    g->loopback = true;
+    if (const char* e = getenv("CHASE_HIP_LOOPBACK_TOUCH")) g->loopback_touch = atoi(e) != 0;
+    *out = g;
+    return 0;
+}
+
 int chase_hip_grid_destroy(chase_hip_grid* g)
 {
     if (!g) return 0;
     if (g->ctx) hipSetDevice(g->ctx->device);
-    if (g->comm_stream) hipStreamSynchronize(g->comm_stream);
+    for (int i = 0; i < 2; ++i)
+        if (g->comm_stream[i]) hipStreamSynchronize(g->comm_stream[i]);
     for (int i = 0; i < 2; ++i)
         if (g->comm[i]) ncclCommDestroy(g->comm[i]);
     if (g->scal_dev) hipFree(g->scal_dev);
-    for (hipEvent_t e : g->slots)
-        if (e) hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i)
+        for (hipEvent_t e : g->slots[i])
+            if (e) hipEventDestroy(e);
     for (auto& pr : g->ev_pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (hipEvent_t e : g->ev_pool) hipEventDestroy(e);
     if (g->ev_compute) hipEventDestroy(g->ev_compute);
-    if (g->ev_comm) hipEventDestroy(g->ev_comm);
-    if (g->comm_stream) hipStreamDestroy(g->comm_stream);
+    for (int i = 0; i < 2; ++i) {
+        if (g->ev_comm[i]) hipEventDestroy(g->ev_comm[i]);
+        if (g->comm_stream[i]) hipStreamDestroy(g->comm_stream[i]);
+    }
     delete g;
     return 0;
 }
+
+/* 1: both groups' collectives on one communication stream (round 4's behaviour); 2 (default): one stream per group.  Only
+ * between collectives: the compute stream first waits for everything issued so far. */
+int chase_hip_grid_set_comm_streams(chase_hip_grid* g, int n)
+{
+    if (!g || (n != 1 && n != 2)) return set_error(CHASE_HIP_EINVAL, "set_comm_streams: 1 or 2");
+    if (n == g->nstreams) return 0;
+    // everything in flight must have landed before the mapping group -> stream changes (slot events included)
+    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamSynchronize(g->comm_stream[i]));
+    g->pending[0] = g->pending[1] = false;
+    g->nstreams = n;
+    return 0;
+}
+int chase_hip_grid_comm_streams(chase_hip_grid* g) { return g ? g->nstreams : 0; }
 
 int chase_hip_grid_group_active(chase_hip_grid* g, int group)
 {
@@ -192,12 +247,20 @@ static int collective(chase_hip_grid* g, int mode, int group, void* dev, size_t 
     if (count == 0 || !g->active(group)) return 0;
     if (mode == 1 && (root < 0 || root >= g->group_size(group))) return set_error(CHASE_HIP_EINVAL, "bcast: bad root");
     chase_hip_ctx* c = g->ctx;
-    if (g->use_rccl) {
-        // comm stream picks up after everything enqueued so far on the compute stream
+    if (c->oplog_on) c->oplog_add(mode == 0 ? "allreduce" : "bcast", group, (long)count, mode == 0 ? 0 : root, async);
+    if (g->async_transport()) {
+        // this group's comm stream picks up after everything enqueued so far on the compute stream
+        hipStream_t cs = g->stream_of(group);
         HIPCHK(hipEventRecord(g->ev_compute, c->stream));
-        HIPCHK(hipStreamWaitEvent(g->comm_stream, g->ev_compute, 0));
-        if (mode == 0) NCCLCHK(ncclAllReduce(dev, dev, count, ncclDouble, ncclSum, g->comm[group], g->comm_stream));
-        else NCCLCHK(ncclBroadcast(dev, dev, count, ncclDouble, root, g->comm[group], g->comm_stream));
+        HIPCHK(hipStreamWaitEvent(cs, g->ev_compute, 0));
+        if (g->use_rccl) {
+            if (mode == 0) NCCLCHK(ncclAllReduce(dev, dev, count, ncclDouble, ncclSum, g->comm[group], cs));
+            else NCCLCHK(ncclBroadcast(dev, dev, count, ncclDouble, root, g->comm[group], cs));
+        } else if (g->loopback_touch) {
+            int rc = loopback_touch_launch(cs, (double*)dev, count);
+            if (rc) return rc;
+        }
+        g->pending[g->stream_index(group)] = true;
         if (!async) return chase_hip_grid_wait(g);
         return 0;
     }
@@ -226,37 +289,69 @@ int chase_hip_grid_bcast(chase_hip_grid* g, int group, void* dev, size_t count, 
 int chase_hip_grid_wait(chase_hip_grid* g)
 {
     if (!g) return set_error(CHASE_HIP_EINVAL, "grid_wait: NULL grid");
-    if (!g->use_rccl) return 0;
-    HIPCHK(hipEventRecord(g->ev_comm, g->comm_stream));
-    return g->wait_on(g->ev_comm);
+    if (!g->async_transport()) return 0;
+    for (int i = 0; i < 2; ++i) {
+        if (!g->pending[i]) continue;                   // nothing issued on that stream since the last wait
+        HIPCHK(hipEventRecord(g->ev_comm[i], g->comm_stream[i]));
+        int rc = g->wait_on(g->ev_comm[i]);
+        if (rc) return rc;
+        g->pending[i] = false;
+    }
+    return 0;
 }
 
 /* slot events: record = "everything issued so far on the communication stream"; wait = the context (compute) stream waits
  * for the last record of that slot (no-op if the slot was never recorded or the transport is synchronous) */
+static int slot_record(chase_hip_grid* g, int si, int slot)
+{
+    auto& v = g->slots[si];
+    while ((int)v.size() <= slot) v.push_back(nullptr);
+    if (!v[slot]) HIPCHK(hipEventCreateWithFlags(&v[slot], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(v[slot], g->comm_stream[si]));
+    return 0;
+}
+/* record on the communication stream of `group` (the collectives of that group issued so far) */
+int chase_hip_grid_event_record_on(chase_hip_grid* g, int group, int slot)
+{
+    if (!g || slot < 0 || (group != CHASE_HIP_ROW && group != CHASE_HIP_COL))
+        return set_error(CHASE_HIP_EINVAL, "event_record: bad argument");
+    if (g->ctx->oplog_on) g->ctx->oplog_add("event_record", group, slot, 0, 0);
+    if (!g->async_transport()) return 0;
+    return slot_record(g, g->stream_index(group), slot);
+}
+/* record on every communication stream */
 int chase_hip_grid_event_record(chase_hip_grid* g, int slot)
 {
     if (!g || slot < 0) return set_error(CHASE_HIP_EINVAL, "event_record: bad argument");
-    if (!g->use_rccl) return 0;
-    while ((int)g->slots.size() <= slot) g->slots.push_back(nullptr);
-    if (!g->slots[slot]) HIPCHK(hipEventCreateWithFlags(&g->slots[slot], hipEventDisableTiming));
-    HIPCHK(hipEventRecord(g->slots[slot], g->comm_stream));
+    if (!g->async_transport()) return 0;
+    for (int si = 0; si < g->nstreams; ++si) { int rc = slot_record(g, si, slot); if (rc) return rc; }
     return 0;
 }
+/* the context stream waits for the last record of that slot on EVERY communication stream */
 int chase_hip_grid_event_wait(chase_hip_grid* g, int slot)
 {
     if (!g || slot < 0) return set_error(CHASE_HIP_EINVAL, "event_wait: bad argument");
-    if (!g->use_rccl || slot >= (int)g->slots.size() || !g->slots[slot]) return 0;
-    return g->wait_on(g->slots[slot]);
+    if (g->ctx->oplog_on) g->ctx->oplog_add("event_wait", slot, 0, 0, 0);
+    if (!g->async_transport()) return 0;
+    for (int si = 0; si < 2; ++si) {
+        if (slot >= (int)g->slots[si].size() || !g->slots[si][slot]) continue;
+        int rc = g->wait_on(g->slots[si][slot]);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int chase_hip_grid_agree_max(chase_hip_grid* g, int* value)
 {
     if (!g || !value) return set_error(CHASE_HIP_EINVAL, "agree_max: NULL argument");
     if (g->nprow * g->npcol == 1 && !g->force) return 0;
+    if (g->ctx->oplog_on) g->ctx->oplog_add("agree_max", 0, 0, 0, 0);
+    if (g->loopback) return 0;                        // nobody to agree with: the replayed rank keeps its own value
     // exact maximum with SUM all-reduces (the one reduction both transports offer): every member of a group writes its
     // value into its own slot of a zeroed vector, the sum is then the list of all values.  Row groups first, column
     // groups on the row maxima second.
     chase_hip_ctx* c = g->ctx;
+    struct Mute { chase_hip_ctx* c; Mute(chase_hip_ctx* x) : c(x) { ++c->oplog_mute; } ~Mute() { --c->oplog_mute; } } mute(c);
     int cur = *value;
     for (int grp : {CHASE_HIP_ROW, CHASE_HIP_COL}) {
         if (!g->active(grp)) continue;
@@ -295,14 +390,32 @@ int chase_hip_grid_sendrecv(chase_hip_grid* g, int group, const void* sendbuf, s
     }
     if (peer_send == me || peer_recv == me) return set_error(CHASE_HIP_EINVAL, "sendrecv: half of a self exchange");
     if (peer_send < 0 && peer_recv < 0) return 0;
+    if (c->oplog_on) c->oplog_add("sendrecv", group, (long)sendcount, (long)recvcount, 0);
+    if (g->loopback) {
+        // what would arrive from the peer has the size of what is sent: keep the buffers defined, move nothing elsewhere
+        hipStream_t cs = g->stream_of(group);
+        HIPCHK(hipEventRecord(g->ev_compute, c->stream));
+        HIPCHK(hipStreamWaitEvent(cs, g->ev_compute, 0));
+        if (peer_recv >= 0) {
+            const size_t n = std::min(sendcount, recvcount);
+            if (peer_send >= 0 && n) HIPCHK(hipMemcpyAsync(recvbuf, sendbuf, n * sizeof(double), hipMemcpyDeviceToDevice, cs));
+            if (recvcount > n || peer_send < 0)
+                HIPCHK(hipMemsetAsync((double*)recvbuf + (peer_send >= 0 ? n : 0), 0,
+                                      (recvcount - (peer_send >= 0 ? n : 0)) * sizeof(double), cs));
+        }
+        g->pending[g->stream_index(group)] = true;
+        return chase_hip_grid_wait(g);
+    }
     if (g->use_rccl) {
         if (!g->comm[group]) return set_error(CHASE_HIP_ECOMM, "sendrecv: group has no communicator");
+        hipStream_t cs = g->stream_of(group);
         HIPCHK(hipEventRecord(g->ev_compute, c->stream));
-        HIPCHK(hipStreamWaitEvent(g->comm_stream, g->ev_compute, 0));
+        HIPCHK(hipStreamWaitEvent(cs, g->ev_compute, 0));
         NCCLCHK(ncclGroupStart());
-        if (peer_send >= 0) NCCLCHK(ncclSend(sendbuf, sendcount, ncclDouble, peer_send, g->comm[group], g->comm_stream));
-        if (peer_recv >= 0) NCCLCHK(ncclRecv(recvbuf, recvcount, ncclDouble, peer_recv, g->comm[group], g->comm_stream));
+        if (peer_send >= 0) NCCLCHK(ncclSend(sendbuf, sendcount, ncclDouble, peer_send, g->comm[group], cs));
+        if (peer_recv >= 0) NCCLCHK(ncclRecv(recvbuf, recvcount, ncclDouble, peer_recv, g->comm[group], cs));
         NCCLCHK(ncclGroupEnd());
+        g->pending[g->stream_index(group)] = true;
         return chase_hip_grid_wait(g);
     }
     if (!g->h_sendrecv) return set_error(CHASE_HIP_ECOMM, "sendrecv: host transport has no send/recv callback");
@@ -330,7 +443,7 @@ int chase_hip_grid_set_profiling(chase_hip_grid* g, int on)
 {
     if (!g) return set_error(CHASE_HIP_EINVAL, "set_profiling: NULL grid");
     if (!on && g->profiling) { int rc = g->collect_exposed(); if (rc) return rc; }
-    g->profiling = on != 0 && g->use_rccl;
+    g->profiling = on != 0 && g->async_transport();
     return 0;
 }
 int chase_hip_grid_comm_exposed_ms(chase_hip_grid* g, double* ms, unsigned long long* waits, int reset)
@@ -346,11 +459,11 @@ int chase_hip_grid_comm_exposed_ms(chase_hip_grid* g, double* ms, unsigned long 
 int chase_hip_grid_transport(chase_hip_grid* g, int* is_rccl, int* row_ranks, int* col_ranks)
 {
     if (!g) return set_error(CHASE_HIP_EINVAL, "grid_transport: NULL grid");
-    if (is_rccl) *is_rccl = g->use_rccl ? 1 : 0;
+    if (is_rccl) *is_rccl = g->use_rccl ? 1 : (g->loopback ? 2 : 0);   /* 0 host callbacks, 1 RCCL, 2 loopback */
     int n[2] = {1, 1};
     for (int i = 0; i < 2; ++i) {
         if (g->use_rccl && g->comm[i]) NCCLCHK(ncclCommCount(g->comm[i], &n[i]));
-        else if (!g->use_rccl) n[i] = g->group_size(i);
+        else if (!g->use_rccl) n[i] = g->loopback ? 1 : g->group_size(i);
     }
     if (row_ranks) *row_ranks = n[CHASE_HIP_ROW];
     if (col_ranks) *col_ranks = n[CHASE_HIP_COL];

@@ -401,7 +401,8 @@ int hh_apply_q_left(chase_hip_ctx* c, bool cplx, const double* Vstore, long ldv,
             unsigned gx = (unsigned)((rows + 1023) / 1024); if (gx > 64) gx = 64; if (gx < 1) gx = 1;
             KL(hipLaunchKernelGGL(extract_v_kernel, dim3(gx, nb), dim3(256), 0, st, Vstore, ldv, m, j0, nb, E, Vb));
             RC(g3(c, cplx, 'C', nb, nb, rows, 1.0, Vb, rows, Vb, rows, 0.0, G, nb));
-            if (hipMemsetAsync(T, 0, (size_t)nb * nb * E * sizeof(double), st) != hipSuccess) return (int)hipGetLastError();
+            if (hipError_t me = hipMemsetAsync(T, 0, (size_t)nb * nb * E * sizeof(double), st); me != hipSuccess)
+                return hip_fail(me, "apply_q: memset T");
             const int nsub = (nb + HNB - 1) / HNB;
             if (cplx) KL(hipLaunchKernelGGL(larft_diag_kernel<true>, dim3(nsub), dim3(64), 0, st, G, nb, nb, tau + (size_t)j0 * E, T, nb));
             else      KL(hipLaunchKernelGGL(larft_diag_kernel<false>, dim3(nsub), dim3(64), 0, st, G, nb, nb, tau + (size_t)j0 * E, T, nb));
@@ -428,6 +429,7 @@ extern "C" int chase_hip_houseqr(chase_hip_ctx* c, int cplx_, int m, int n, void
 {
     if (!c || !V_) return set_error(CHASE_HIP_EINVAL, "houseqr: NULL argument");
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("houseqr", m, n, 0, 0);
     if (m < n || n < 0 || ldv < m) return set_error(CHASE_HIP_EINVAL, "houseqr: need m >= n and ldv >= m");
     if (n == 0) return 0;
     const bool cplx = cplx_ != 0;
@@ -511,6 +513,7 @@ extern "C" int chase_hip_houseqr_dist(chase_hip_ctx* c, chase_hip_grid* grid, in
 {
     if (!c || !grid || (!V_ && mloc > 0)) return set_error(CHASE_HIP_EINVAL, "houseqr_dist: NULL argument");
     (void)hipSetDevice(c->device);
+    if (c->oplog_on) c->oplog_add("houseqr_dist", mloc, n, group, 0);
     if (mloc < 0 || n < 0 || ldv < mloc || row_offset < 0) return set_error(CHASE_HIP_EINVAL, "houseqr_dist: bad shape");
     if (n == 0) return 0;
     const bool cplx = cplx_ != 0;

@@ -1,6 +1,7 @@
 // vec_kernels.hip — HBM-bound O(N*n) kernels of the ChASE hot path (wave64 shuffle reductions, 16-byte accesses)
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdio>
 #include "kernels.h"
 #include "ctx.h"
 #include "../../include/chase_hip.h"
@@ -9,6 +10,8 @@ int chase_hip_ctx::gemm(bool cplx, char opA, int m, int n, int k, const double* 
                         const double* B, long ldb, const double* beta, double* C, long ldc)
 {
     if (m <= 0 || n <= 0) return 0;
+    if (oplog_on) oplog_add(cplx ? (opA == 'N' ? "gemm_zN" : "gemm_zC") : (opA == 'N' ? "gemm_dN" : "gemm_dC"), m, n, k,
+                            phase * 100 + gemm_min_rounds);
     // workspace: what this shape's tail split can use (never the whole fixed cap up front), at least 8 MB so that the
     // ragged-column launch is always available
     const size_t need = std::max(chase_hip::gemm_f64_ws_need(cplx, opA, m, n, k, num_cu, gemm_min_rounds), (size_t)8 << 20);
@@ -23,6 +26,14 @@ int chase_hip_ctx::gemm(bool cplx, char opA, int m, int n, int k, const double* 
     flops_model[ph] += 2.0 * (cplx ? 4.0 : 1.0) * m * (double)n * k;
     ++gemm_calls[ph];
     return 0;
+}
+
+void chase_hip_ctx::oplog_add(const char* name, long a, long b, long c, long d)
+{
+    if (!oplog_on || oplog_mute > 0) return;
+    char buf[160];
+    snprintf(buf, sizeof buf, "%s %ld %ld %ld %ld", name, a, b, c, d);
+    oplog.emplace_back(buf);
 }
 
 int chase_hip_ctx::ensure_ws(size_t bytes)

@@ -13,6 +13,12 @@ _sig("chase_hip_grid_create_rccl", c_int, P(c_void_p), c_void_p, c_int, c_int, c
 AR_FN = C.CFUNCTYPE(c_int, c_void_p, c_int, P(c_double), c_size_t)
 BC_FN = C.CFUNCTYPE(c_int, c_void_p, c_int, P(c_double), c_size_t, c_int)
 _sig("chase_hip_grid_create_host", c_int, P(c_void_p), c_void_p, c_int, c_int, c_int, AR_FN, BC_FN, c_void_p)
+_sig("chase_hip_grid_create_loopback", c_int, P(c_void_p), c_void_p, c_int, c_int, c_int)
+_sig("chase_hip_grid_set_comm_streams", c_int, c_void_p, c_int)
+_sig("chase_hip_grid_comm_streams", c_int, c_void_p)
+_sig("chase_hip_grid_event_record_on", c_int, c_void_p, c_int, c_int)
+_sig("chase_hip_grid_event_record", c_int, c_void_p, c_int)
+_sig("chase_hip_grid_event_wait", c_int, c_void_p, c_int)
 _sig("chase_hip_grid_destroy", c_int, c_void_p)
 _sig("chase_hip_grid_group_active", c_int, c_void_p, c_int)
 _sig("chase_hip_grid_info", c_int, c_void_p, P(c_int), P(c_int), P(c_int), P(c_int))
@@ -140,6 +146,9 @@ class Grid:
                 ids2 = [bytes(my_id2.raw)]
             check(lib.chase_hip_grid_create_rccl(C.byref(h), ctx.h, nprow, npcol, rank, ids[row_leader],
                                                  ids2[col_leader]), "grid_create_rccl")
+        elif transport == "loopback":
+            # ONE rank of the grid with nobody on the other side (single-rank replay, chase_hip_grid_create_loopback)
+            check(lib.chase_hip_grid_create_loopback(C.byref(h), ctx.h, nprow, npcol, rank), "grid_create_loopback")
         else:
             # host-callback transport (test plumbing): `pg` is either the dict of torch.distributed groups made by
             # make_process_groups (ranks = processes, payloads through gloo) or any object with
@@ -196,7 +205,14 @@ class Grid:
         """(is_rccl, ranks RCCL reports for the row communicator, for the column communicator)"""
         a, r, c = c_int(), c_int(), c_int()
         check(lib.chase_hip_grid_transport(self.h, C.byref(a), C.byref(r), C.byref(c)), "grid_transport")
-        return bool(a.value), r.value, c.value
+        return a.value == 1, r.value, c.value
+
+    def set_comm_streams(self, n):
+        """1: both groups' collectives on one communication stream, 2: one stream per group (default)."""
+        check(lib.chase_hip_grid_set_comm_streams(self.h, int(n)), "set_comm_streams")
+
+    def comm_streams(self):
+        return lib.chase_hip_grid_comm_streams(self.h)
 
     def sendrecv(self, group, send, peer_send, recv, peer_recv):
         """send / recv: DeviceArray (or None); counts in doubles are taken from the arrays"""

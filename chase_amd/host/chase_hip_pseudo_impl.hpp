@@ -21,6 +21,7 @@
 #include "../../include/chase_hip.h"
 #include "chase_hip_impl.hpp"
 #include "interface.hpp"
+#include "roctx.hpp"
 
 namespace chase_amd {
 
@@ -90,6 +91,7 @@ public:
 
     void initVecs(bool random) override
     {
+        CHASE_PHASE(ctx_, "initVecs");
         if (random && device_rng_) {
             hip_ok(chase_hip_fill_normal(ctx_, CP, (int)N_, (int)nc_, dV1_, (long)N_, 0, 0, (long)N_, 1337ull), "fill_normal");
         } else {
@@ -111,6 +113,7 @@ public:
     // chase_cpu.hpp:329-349: re-randomise the given columns (offset by fixednev) of V1 from mt19937(4242) and mirror to V2
     void ReinitColumns(std::size_t fixednev, std::size_t const* col_indices, std::size_t n_indices) override
     {
+        CHASE_PHASE(ctx_, "ReinitColumns");
         if (n_indices == 0) return;
         flush_swaps();
         
@@ -128,12 +131,14 @@ public:
 
     void End() override
     {
+        CHASE_PHASE(ctx_, "End");
         flush_swaps();
         hip_ok(chase_hip_download_matrix(ctx_, CP, (int)N_, (int)nc_, dV1_, (long)N_, V1_, (long)ldv_), "download V");
     }
 
     void FilterPhaseStart() override
     {
+        roctx_push("chase:Filter");
         flush_swaps();
         chase_hip_ctx_set_phase(ctx_, 1);
         hip_ok(chase_hip_timer_start(ctx_), "timer");
@@ -144,6 +149,7 @@ public:
         hip_ok(chase_hip_timer_stop(ctx_, &ms), "timer");
         chase_hip_ctx_set_phase(ctx_, 0);
         filter_ms_ += ms;
+        roctx_pop(ctx_);
     }
 
     void HEMM_H2(std::size_t block, T alpha, T beta, T gamma, std::size_t offset_left, std::size_t offset_right = 0) override
@@ -170,6 +176,7 @@ public:
 
     void ApplyKconjugate(std::size_t block) override
     {
+        CHASE_PHASE(ctx_, "ApplyKconjugate");
         flush_swaps();
         const std::size_t h = N_ / 2, c2 = nc_ - locked_ - block;
         T* first = dV1_ + locked_ * N_;
@@ -181,6 +188,7 @@ public:
 
     void QR(std::size_t, R cond) override
     {
+        CHASE_PHASE(ctx_, "QR");
         flush_swaps();
         const std::size_t L = locked_;
         const int n = (int)N_;
@@ -215,6 +223,7 @@ public:
 
     void RR(R* ritzv, std::size_t block) override
     {
+        CHASE_PHASE(ctx_, "RR");
         flush_swaps();
         const std::size_t n = 2 * block, k = N_ / 2;
         T* Q = dV1_ + locked_ * N_;
@@ -238,6 +247,7 @@ public:
 
     void Resd(R* ritzv, R* resd, std::size_t) override
     {
+        CHASE_PHASE(ctx_, "Resd");
         flush_swaps();
         const std::size_t sub = nevex_ - locked_;
         T* V = dV1_ + locked_ * N_;
@@ -251,6 +261,7 @@ public:
 
     void recompute_residuals(std::size_t ncols, const double* lambda, double* out) override
     {
+        CHASE_PHASE(ctx_, "recompute_residuals");
         if (ncols > 2 * nevex_) throw std::invalid_argument("recompute_residuals: more columns than the Impl holds");
         flush_swaps();
         chase_hip_ctx_set_phase(ctx_, 3);
@@ -269,6 +280,7 @@ public:
 
     void Lanczos(std::size_t m, R* upperb) override
     {
+        CHASE_PHASE(ctx_, "Lanczos");
         lanczosIter_ = m; numLanczos_ = 1;
         std::vector<R> theta(m), tau(m), z(m * m);
         lanczos_core(m, 1, false, theta.data(), tau.data(), z.data());
@@ -276,12 +288,14 @@ public:
     }
     void Lanczos(std::size_t M, std::size_t numvec, R* upperb, R* ritzv, R* Tau, R* ritzV) override
     {
+        CHASE_PHASE(ctx_, "Lanczos");
         lanczosIter_ = M; numLanczos_ = numvec;
         lanczos_core(M, numvec, true, ritzv, Tau, ritzV);
         if (upperb) *upperb = ritzv[M - 1];                   // cpu/lanczos.hpp:515
     }
     void LanczosDos(std::size_t idx, std::size_t m, T* ritzVc) override
     {
+        CHASE_PHASE(ctx_, "LanczosDos");
         flush_swaps();
         hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)m, (int)idx, ritzVc, (long)m, dA_, (long)m), "upload ritzV");
         gemm('N', N_, idx, m, T(1), dV1_, N_, dA_, m, T(0), dV2_, N_);

@@ -36,6 +36,7 @@
 #include "../../include/chase_hip_grid.h"
 #include "chase_hip_impl.hpp"
 #include "interface.hpp"
+#include "roctx.hpp"
 
 namespace chase_amd {
 
@@ -88,7 +89,8 @@ public:
         // staging must hold the largest block of ANY rank (rank 0 of a dimension owns the most rows)
         // staging of the column <-> row redistribution: the pieces of ALL source ranks side by side (they add up to the rows
         // of the destination block), so that the broadcasts can be in flight together
-        alloc((void**)&dStage_, (std::size_t)std::max(std::max(Rr_.count(0), Cc_.count(0)), (long)std::max(m_, n_)) * nc_ * sizeof(T));
+        stage_rows_ = (std::size_t)std::max(std::max(Rr_.count(0), Cc_.count(0)), (long)std::max(m_, n_));
+        alloc((void**)&dStage_, stage_rows_ * nc_ * sizeof(T));
         dHbac_ = dH_; ldhbac_ = ldh_;
         // column panel of the pipelined HEMM: a panel's GEMM should fill the chip once with whole output tiles
         // (128-row tiles x 64 / 128 columns, two workgroups on each of the 256 CUs) in both directions; the panel grid is
@@ -101,6 +103,14 @@ public:
         }
         build_diag_lists();
         build_redistribution();
+        {   // on a loopback grid (single-rank replay, chase_hip_grid_create_loopback) the pieces "received" from absent peers are
+            // whatever the staging block held: start it from N(0,1) so that they are finite, data-like numbers
+            int kind = 0;
+            hip_ok(chase_hip_grid_transport(grid_, &kind, nullptr, nullptr), "grid_transport");
+            loopback_ = kind == 2;
+            if (loopback_ && stage_rows_ > 0)
+                hip_ok(chase_hip_fill_normal(ctx_, CP, (int)stage_rows_, (int)nc_, dStage_, (long)stage_rows_, 0, 0, (long)stage_rows_, 99ull), "fill staging");
+        }
     }
     ~pChaseHip() override { for (void* p : owned_) chase_hip_free(ctx_, p); }
 
@@ -124,6 +134,7 @@ public:
     // group), compared elementwise with the reference's absolute 1e-10 after bringing u back to the column-type layout
     bool checkSymmetryEasy() override
     {
+        CHASE_PHASE(ctx_, "checkSymmetryEasy");
         flush_swaps(); sync_comm();
         void* blk = nullptr;
         const std::size_t elems = 3 * m_ + 2 * n_;
@@ -183,6 +194,7 @@ public:
     // pchase_cpu.hpp:272-311: every grid row seeds mt19937(1337 + coords[0]) and fills its block in memory order
     void initVecs(bool random) override
     {
+        CHASE_PHASE(ctx_, "initVecs");
         hv_valid_ = false;
         if (random) {
             if (device_rng_) {
@@ -215,6 +227,7 @@ public:
     // pchase_cpu.hpp:313-331: re-randomise the given columns (offset by fixednev) of the local V1 block, mirror to V2
     void ReinitColumns(std::size_t fixednev, std::size_t const* col_indices, std::size_t n_indices) override
     {
+        CHASE_PHASE(ctx_, "ReinitColumns");
         if (n_indices == 0) return;
         flush_swaps();
         sync_comm(); hv_valid_ = false;
@@ -235,6 +248,7 @@ public:
     // ---- filter --------------------------------------------------------------------------------------------------------
     void FilterPhaseStart() override
     {
+        roctx_push("chase:Filter");
         flush_swaps();
         chase_hip_ctx_set_phase(ctx_, 1);
         hip_ok(chase_hip_timer_start(ctx_), "timer");
@@ -246,6 +260,7 @@ public:
         hip_ok(chase_hip_timer_stop(ctx_, &ms), "timer");
         chase_hip_ctx_set_phase(ctx_, 0);
         filter_ms_ += ms;
+        roctx_pop(ctx_);
     }
 
     // mpi/shiftDiagonal.hpp:21-78 / cuda/shiftDiagonal.cu:100-149: shift the locally owned diagonal entries
@@ -290,6 +305,7 @@ public:
     // ---- QR (pchase_cpu.hpp:572-867) -------------------------------------------------------------------------------------
     void QR(std::size_t, R cond) override
     {
+        CHASE_PHASE(ctx_, "QR");
         flush_swaps(); sync_comm(); hv_valid_ = false;
         hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)locked_, dV1_, (long)m_, dV2_, (long)m_), "lacpy");
         int disable = config_.DoCholQR() ? 0 : 1;
@@ -312,6 +328,7 @@ public:
     // ---- Rayleigh-Ritz (mpi/rayleighRitz.hpp:103-186 + pchase_cpu.hpp:869-896) ------------------------------------------
     void RR(R* ritzv, std::size_t block) override
     {
+        CHASE_PHASE(ctx_, "RR");
         flush_swaps(); sync_comm();
         const std::size_t c0 = locked_;
         // Like the reference (pchase_gpu.hpp:1631-1633), V is re-broadcast inside the row group so that the replicas over the
@@ -323,18 +340,27 @@ public:
         static const bool resync = [] { const char* e = std::getenv("CHASE_HIP_RR_RESYNC"); return e ? std::atoi(e) != 0 : true; }();
         if (resync && npcol_ > 1) coll(chase_hip_grid_bcast(grid_, CHASE_HIP_ROW, dV1_ + c0 * m_, m_ * block * E, 0, 0));
         hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)block, dV1_ + c0 * m_, (long)m_, dV2_ + c0 * m_, (long)m_), "lacpy");
+        // round 5: the column -> row redistribution of V (its packed broadcasts run inside the COLUMN group, like the product's
+        // all-reduces) is ISSUED FIRST: it does not depend on the product, and queued behind the last all-reduce panel (round 4)
+        // it was pure exposed time.  Now the broadcasts run beside the first panel's GEMM; the unpack waits for them below.
+        redistribute_start(c2r_, CHASE_HIP_COL, myrow_, dV2_ + c0 * m_, m_, block);
         chase_hip_ctx_set_phase(ctx_, 2);                                    // H-times-block product outside the filter
         // panel-pipelined like the filter's products (round 4): the all-reduce of column panel p (1.34 GB in all at config 4 on
-        // 4 x 2) runs beside the GEMM of panel p + 1; the redistribution below queues behind it on the communication stream
-        // and its wait covers both
+        // 4 x 2) runs beside the GEMM of panel p + 1
         hemm_dir(true, c0, block, T(1), T(0), true);                         // W1 = H^H V1 (row-type), all-reduced
         chase_hip_ctx_set_phase(ctx_, 0);
-        redistribute_c2r(dV2_ + c0 * m_, dW2_ + c0 * n_, block);             // W2 = V2 in the row-type layout (waits for the stream)
+        redistribute_finish(c2r_, dW2_ + c0 * n_, n_, block);                // W2 = V2 in the row-type layout (waits for the streams)
         // A = V^H (H V), Hermitian: only the upper block trapezoid is multiplied, packed and summed over the row group
         hip_ok(chase_hip_herkx(ctx_, CP, (int)block, (int)n_, dW2_ + c0 * n_, (long)n_, dW1_ + c0 * n_, (long)n_, dA_, (long)block, 0), "herkx");
-        allreduce_packed_upper(dA_, block, CHASE_HIP_ROW);
+        // Identical Ritz pairs on every rank by identical INPUT (round 5; rounds 2-4 broadcast the 105 MB eigenvector matrix
+        // from rank (0,0) after the eigensolver): the packed triangle is summed over the row group - every member of a row
+        // group then holds the same bits - and broadcast once from grid row 0 inside the column groups (52 MB at config 4), so
+        // that every rank feeds the same matrix to the eigensolver, whose kernels and host stages are deterministic
+        // (tests: bitwise equal replicas across ranks).  CHASE_HIP_RR_AGREE=vectors restores the broadcast of the result.
+        static const bool agree_vectors = [] { const char* e = std::getenv("CHASE_HIP_RR_AGREE"); return e && std::string(e) == "vectors"; }();
+        allreduce_packed_upper(dA_, block, CHASE_HIP_ROW, agree_vectors ? -1 : CHASE_HIP_COL);
         hip_ok(chase_hip_heevd(ctx_, CP, (int)block, dA_, (long)block, ritzv), "heevd");
-        agree_vector(ritzv, block, dA_, block * block);                      // identical Ritz pairs on every rank
+        if (agree_vectors) agree_vector(ritzv, block, dA_, block * block);
         hv_valid_ = false;
         if (resd_reuse_) {
             // row-type H V and V of the new Ritz vectors without another HEMM / all-reduce / redistribution:
@@ -347,35 +373,46 @@ public:
         }
         gemm('N', m_, block, block, T(1), dV2_ + c0 * m_, m_, dA_, block, T(0), dV1_ + c0 * m_, m_);
         hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)block, dV1_ + c0 * m_, (long)m_, dV2_ + c0 * m_, (long)m_), "lacpy");
+        // the Ritz VALUES still go round (2560 doubles, behind the back-transformation's launches): they steer every rank's
+        // control flow, and a rank whose host LAPACK stage rounded differently must not take another branch
+        if (!agree_vectors) agree_vector(ritzv, block, nullptr, 0);
     }
 
     // ---- residuals (mpi/residuals.hpp:61-107) ----------------------------------------------------------------------------
     void Resd(R* ritzv, R* resd, std::size_t) override
     {
+        CHASE_PHASE(ctx_, "Resd");
         flush_swaps(); sync_comm();
         const std::size_t c0 = locked_, sub = nevex_ - locked_;
         const T *HV, *Vr;
         if (hv_valid_ && hv_shift_ == 0.0 && hv_locked_ == locked_ && hv_block_ == sub) {   // left behind by RR
             HV = dW3_ + c0 * n_; Vr = dW1_ + c0 * n_;
         } else {
+            redistribute_start(c2r_, CHASE_HIP_COL, myrow_, dV2_ + c0 * m_, m_, sub);   // V2 (== V1) -> row-type, issued first (see RR)
             chase_hip_ctx_set_phase(ctx_, 2);
             hemm_dir(true, c0, sub, T(1), T(0), true);                       // W1 = H^H V1 (panel-pipelined, see RR)
             chase_hip_ctx_set_phase(ctx_, 0);
-            redistribute_c2r(dV2_ + c0 * m_, dW2_ + c0 * n_, sub);           // W2 = V2 (== V1) row-type (waits for the stream)
+            redistribute_finish(c2r_, dW2_ + c0 * n_, n_, sub);              // W2 = V2 row-type (waits for the streams)
             HV = dW1_ + c0 * n_; Vr = dW2_ + c0 * n_;
             hv_valid_ = false;                                               // dW1_ no longer holds the cached V
         }
-        hip_ok(chase_hip_resid_norms(ctx_, CP, (int)n_, (int)sub, HV, (long)n_, Vr, (long)n_,
-                                     ritzv, resd, 1), "resid_norms");      // local sums of squares
-        // all-reduce over the row communicator, then sqrt (mpi/residuals.hpp:99-105)
-        double* d = (double*)dPack_;
-        hip_ok(chase_hip_memcpy_h2d(ctx_, d, resd, sub * sizeof(double)), "h2d");
-        coll(chase_hip_grid_allreduce(grid_, CHASE_HIP_ROW, d, sub, 0));
-        hip_ok(chase_hip_memcpy_d2h(ctx_, resd, d, sub * sizeof(double)), "d2h");
-        for (std::size_t i = 0; i < sub; ++i) resd[i] = std::sqrt(resd[i]);
-        agree_vector(resd, sub, nullptr, 0);
+        sum_resid_squares(HV, Vr, ritzv, resd, sub);
         recheck_borderline(ritzv, resd, sub);
         if (resd != resid_.data() + locked_) std::memcpy(resid_.data() + locked_, resd, sub * sizeof(R));
+    }
+
+    // out[j] = || HV_j - lambda_j Vr_j ||_2 of row-type blocks: local sums of squares, all-reduce over the row communicator,
+    // sqrt (mpi/residuals.hpp:99-105).  Round 5: the sums stay on the device across the all-reduce (nccl/residuals.hpp:28-88
+    // does the same) and are made identical on every rank by ONE broadcast from grid row 0 inside the column groups - the
+    // members of a row group hold the same bits after their all-reduce -; one read-back instead of three host round trips.
+    void sum_resid_squares(const T* HV, const T* Vr, const R* lambda, R* out, std::size_t cnt)
+    {
+        double* d = (double*)dPack_;
+        hip_ok(chase_hip_resid_norms_dev(ctx_, CP, (int)n_, (int)cnt, HV, (long)n_, Vr, (long)n_, lambda, d, 1), "resid_norms");
+        coll(chase_hip_grid_allreduce(grid_, CHASE_HIP_ROW, d, cnt, 0));
+        coll(chase_hip_grid_bcast(grid_, CHASE_HIP_COL, d, cnt, 0, 0));
+        hip_ok(chase_hip_memcpy_d2h(ctx_, out, d, cnt * sizeof(double)), "d2h");
+        for (std::size_t i = 0; i < cnt; ++i) out[i] = std::sqrt(out[i]);
     }
 
     // Lock on what the reference would see (see ChaseHip::recheck_borderline): residuals within 1e-3 of the tolerance are
@@ -387,11 +424,28 @@ public:
         static const bool on = [] { const char* e = std::getenv("CHASE_HIP_RESD_RECHECK"); return e ? std::atoi(e) != 0 : true; }();
         if (!on) return;
         const R tol = (R)config_.GetTol();
+        // the window is the larger of 1e-3 tol and the rounding gap between the three-product / cached residual and the
+        // reference's fresh one (measured at config 4: 0.2 eps ||H||; window 4 eps ||H||, ||H|| from the Lanczos upper bound;
+        // independent of tol - the advisor's finding)
+        const R window = std::max((R)1e-3 * tol, (R)4 * std::numeric_limits<R>::epsilon() * norm_h_);
         std::vector<std::size_t> idx;
-        for (std::size_t j = 0; j < sub; ++j)
-            if (std::abs(resd[j] - tol) <= (R)1e-3 * tol) idx.push_back(j);
+        if (forced_recheck_ >= 0) {                                        // single-rank replay: as many as the recording re-took
+            for (std::size_t j = 0; j < std::min<std::size_t>((std::size_t)forced_recheck_, sub); ++j) idx.push_back(j);
+        } else {
+            for (std::size_t j = 0; j < sub; ++j)
+                if (std::abs(resd[j] - tol) <= window) idx.push_back(j);
+        }
         const std::size_t k = idx.size();
-        if (k == 0 || k > 256 || k > nc_) return;
+        if (k == 0) return;
+        if (k > 256 || k > nc_) {
+            // too many for the scratch: the reference's residual step as it stands on ALL unlocked columns (fresh four-product
+            // H V) instead of keeping values the window says may differ from the reference's
+            std::vector<R> fresh(sub);
+            fresh_residuals(locked_, sub, ritzv, fresh.data());
+            std::memcpy(resd, fresh.data(), sub * sizeof(R));
+            resd_rechecked_ += sub;
+            return;
+        }
         if (chk_cols_ < 2 * k) {                                           // row-type scratch: H v and v of the k columns
             const std::size_t cols = (2 * k + 31) / 32 * 32;
             alloc((void**)&dChk_, n_ * cols * sizeof(T));                 // (grow-only; an outgrown block lives until the Impl dies)
@@ -408,37 +462,32 @@ public:
         hemm_ptr(true, dVt_, HVr, 0, k, T(1), T(0), false);
         chase_hip_ctx_set_phase(ctx_, 0);
         redistribute_c2r(dVt_, Vr, k);
-        hip_ok(chase_hip_resid_norms(ctx_, CP, (int)n_, (int)k, HVr, (long)n_, Vr, (long)n_, lam.data(), sq.data(), 1), "resid_norms");
-        double* d = (double*)dPack_;
-        hip_ok(chase_hip_memcpy_h2d(ctx_, d, sq.data(), k * sizeof(double)), "h2d");
-        coll(chase_hip_grid_allreduce(grid_, CHASE_HIP_ROW, d, k, 0));
-        hip_ok(chase_hip_memcpy_d2h(ctx_, sq.data(), d, k * sizeof(double)), "d2h");
-        for (std::size_t i = 0; i < k; ++i) sq[i] = std::sqrt(sq[i]);
-        agree_vector(sq.data(), k, nullptr, 0);
+        sum_resid_squares(HVr, Vr, lam.data(), sq.data(), k);
         for (std::size_t i = 0; i < k; ++i) resd[idx[i]] = sq[i];
         resd_rechecked_ += k;
     }
+    // the reference's residual step as it stands (mpi/residuals.hpp:61-107) on columns [c0, c0 + cnt): fresh four-product H V
+    void fresh_residuals(std::size_t c0, std::size_t cnt, const R* lambda, R* out)
+    {
+        hv_valid_ = false;                                                   // dW1_ / dW2_ are scratch from here on
+        hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)cnt, dV1_ + c0 * m_, (long)m_, dV2_ + c0 * m_, (long)m_), "lacpy");
+        chase_hip_ctx_set_phase(ctx_, 3);
+        hemm_ptr(true, dV1_ + c0 * m_, dW1_ + c0 * n_, 0, cnt, T(1), T(0), false);
+        chase_hip_ctx_set_phase(ctx_, 0);
+        redistribute_c2r(dV2_ + c0 * m_, dW2_ + c0 * n_, cnt);
+        sum_resid_squares(dW1_ + c0 * n_, dW2_ + c0 * n_, lambda, out, cnt);
+    }
+    void set_forced_recheck(long k) override { forced_recheck_ = k; }
     std::size_t resd_rechecked() const override { return resd_rechecked_; }
 
     // the reference's residual step as it stands (mpi/residuals.hpp:61-107: H V, column -> row redistribution of V, local
     // sums of squares, all-reduce over the row group) on the first ncols vectors, never from cached products
     void recompute_residuals(std::size_t ncols, const double* lambda, double* out) override
     {
+        CHASE_PHASE(ctx_, "recompute_residuals");
         if (ncols > nc_) throw std::invalid_argument("recompute_residuals: more columns than the Impl holds");
         flush_swaps(); sync_comm();
-        hv_valid_ = false;                                                   // dW1_ / dW2_ are scratch from here on
-        hip_ok(chase_hip_lacpy(ctx_, CP, (int)m_, (int)ncols, dV1_, (long)m_, dV2_, (long)m_), "lacpy");
-        chase_hip_ctx_set_phase(ctx_, 3);                                    // four real products per complex product, always
-        hemm_ptr(true, dV1_, dW1_, 0, ncols, T(1), T(0), false);             // W1 = H^H V1 (row-type), all-reduced
-        chase_hip_ctx_set_phase(ctx_, 0);
-        redistribute_c2r(dV2_, dW2_, ncols);
-        std::vector<double> sq(ncols);
-        hip_ok(chase_hip_resid_norms(ctx_, CP, (int)n_, (int)ncols, dW1_, (long)n_, dW2_, (long)n_, lambda, sq.data(), 1), "resid_norms");
-        double* d = (double*)dPack_;
-        hip_ok(chase_hip_memcpy_h2d(ctx_, d, sq.data(), ncols * sizeof(double)), "h2d");
-        coll(chase_hip_grid_allreduce(grid_, CHASE_HIP_ROW, d, ncols, 0));
-        hip_ok(chase_hip_memcpy_d2h(ctx_, sq.data(), d, ncols * sizeof(double)), "d2h");
-        for (std::size_t i = 0; i < ncols; ++i) out[i] = std::sqrt(sq[i]);
+        fresh_residuals(0, ncols, lambda, out);
     }
 
     void Swap(std::size_t i, std::size_t j) override
@@ -452,17 +501,20 @@ public:
     // ---- Lanczos (mpi/lanczos.hpp:153-370) ---------------------------------------------------------------------------------
     void Lanczos(std::size_t m, R* upperb) override
     {
+        CHASE_PHASE(ctx_, "Lanczos");
         lanczosIter_ = m; numLanczos_ = 1;
         std::vector<R> theta(m);
         lanczos_core(m, 1, false, upperb, theta.data(), nullptr, nullptr);
     }
     void Lanczos(std::size_t M, std::size_t numvec, R* upperb, R* ritzv, R* Tau, R* ritzV) override
     {
+        CHASE_PHASE(ctx_, "Lanczos");
         lanczosIter_ = M; numLanczos_ = numvec;
         lanczos_core(M, numvec, true, upperb, ritzv, Tau, ritzV);
     }
     void LanczosDos(std::size_t idx, std::size_t m, T* ritzVc) override
     {
+        CHASE_PHASE(ctx_, "LanczosDos");
         flush_swaps(); sync_comm(); hv_valid_ = false;
         hip_ok(chase_hip_upload_matrix(ctx_, CP, (int)m, (int)idx, ritzVc, (long)m, dA_, (long)m), "upload ritzV");
         gemm('N', m_, idx, m, T(1), dV1_, m_, dA_, m, T(0), dV2_, m_);
@@ -553,6 +605,14 @@ protected:
     void redistribute(const std::vector<Xfer>& plan, int group, int me, const T* src, std::size_t lds, T* dst, std::size_t ldd,
                       std::size_t ncols)
     {
+        redistribute_start(plan, group, me, src, lds, ncols);
+        redistribute_finish(plan, dst, ldd, ncols);
+    }
+    // first half: pack my piece, issue every source rank's broadcast on the group's communication stream (asynchronous: the
+    // caller may enqueue independent work - RR and Resd put their whole H-times-block product here - before it asks for the
+    // result).  The staging block is in use until redistribute_finish.
+    void redistribute_start(const std::vector<Xfer>& plan, int group, int me, const T* src, std::size_t lds, std::size_t ncols)
+    {
         std::size_t off = 0;
         for (const Xfer& x : plan) {
             T* piece = dStage_ + off;
@@ -561,8 +621,12 @@ protected:
             coll(chase_hip_grid_bcast(grid_, group, piece, (std::size_t)x.cnt * ncols * E, x.root, 1));
             off += (std::size_t)x.cnt * ncols;
         }
+    }
+    // second half: ONE wait of the compute stream for the communication streams, then the scatter into the destination layout
+    void redistribute_finish(const std::vector<Xfer>& plan, T* dst, std::size_t ldd, std::size_t ncols)
+    {
         sync_comm();
-        off = 0;
+        std::size_t off = 0;
         for (const Xfer& x : plan) {
             hip_ok(chase_hip_rows_indexed(ctx_, CP, dStage_ + off, x.cnt, dst, (long)ldd, x.d_dst, x.cnt, (int)ncols, 1), "unpack");
             off += (std::size_t)x.cnt * ncols;
@@ -620,7 +684,7 @@ protected:
                 coll(chase_hip_grid_allreduce(grid_, group, out + c * out_ld, out_ld * w * E, pipe ? 1 : 0));
                 // (an inactive direction records nothing: its output panel is ordered by the compute stream itself, and the
                 // slot keeps the other direction's last event, which this product has already waited for)
-                if (pipe) coll(chase_hip_grid_event_record(grid_, (int)fp));
+                if (pipe) coll(chase_hip_grid_event_record_on(grid_, group, (int)fp));
             }
             c = cend;
         }
@@ -635,11 +699,15 @@ protected:
         hip_ok(chase_hip_scale_rows_bc(ctx_, CP, (int)n_, (int)ncols, X, (long)n_, (long)(N_ / 2), Cc_.nb, npcol_, mycol_, -1.0), "flip");
     }
 
-    // A (n x n, Hermitian, device) <- sum over `group` of A, moving only the packed upper triangle
-    void allreduce_packed_upper(T* A, std::size_t n, int group)
+    // A (n x n, Hermitian, device) <- sum over `group` of A, moving only the packed upper triangle; agree_group >= 0: the sum
+    // is then broadcast from member 0 of that (other) group, so that every rank of the grid holds the same bits
+    void allreduce_packed_upper(T* A, std::size_t n, int group, int agree_group = -1)
     {
         hip_ok(chase_hip_pack_upper(ctx_, CP, (int)n, A, (long)n, dPack_), "pack_upper");
+        // (both synchronous: the two groups' collectives run on different communication streams, and the compute stream's
+        // wait in between is what orders the broadcast behind the sum)
         coll(chase_hip_grid_allreduce(grid_, group, dPack_, n * (n + 1) / 2 * E, 0));
+        if (agree_group >= 0) coll(chase_hip_grid_bcast(grid_, agree_group, dPack_, n * (n + 1) / 2 * E, 0, 0));
         hip_ok(chase_hip_unpack_upper(ctx_, CP, (int)n, dPack_, A, (long)n, 1), "unpack_upper");
     }
 
@@ -789,6 +857,7 @@ protected:
             if (Tau) { std::memcpy(Tau, pack.data() + o, M * nv * sizeof(R)); o += M * nv; }
             if (ritzV) std::memcpy(ritzV, pack.data() + o, M * M * sizeof(R));
             *upperb = ub;
+            norm_h_ = std::abs(ub);
         } catch (...) {
             if (blk) chase_hip_free(ctx_, blk);
             throw;
@@ -823,6 +892,9 @@ protected:
     double hv_shift_ = 0.0;
     T* dW3_ = nullptr;
     T* dChk_ = nullptr; std::size_t chk_cols_ = 0, resd_rechecked_ = 0;   // scratch of recheck_borderline
+    long forced_recheck_ = -1;                                            // set_forced_recheck (single-rank replay)
+    R norm_h_ = 0;                                                        // Lanczos upper bound of the last solve (recheck window)
+    bool loopback_ = false; std::size_t stage_rows_ = 0;
     T *dV1_ = nullptr, *dV2_ = nullptr, *dVt_ = nullptr, *dW1_ = nullptr, *dW2_ = nullptr, *dA_ = nullptr;
     T *dPack_ = nullptr, *dStage_ = nullptr;
     std::size_t pack_elems_ = 0;

@@ -101,6 +101,7 @@ public:
     // from the rank s rows back; N even makes the row pairing an involution, so the two lists of a pair match.
     void ApplyKconjugate(std::size_t block) override
     {
+        CHASE_PHASE(this->ctx_, "ApplyKconjugate");
         this->flush_swaps(); this->sync_comm();
         if (block == 0) return;
         if (block > this->nevex_) throw std::invalid_argument("ApplyKconjugate: block larger than nev+nex");
@@ -131,6 +132,7 @@ public:
 
     void QR(std::size_t, R cond) override
     {
+        CHASE_PHASE(this->ctx_, "QR");
         this->flush_swaps(); this->sync_comm();
         const std::size_t L = this->locked_, m = this->m_, nc = this->nc_;
         lacpy(L, this->dV1_, this->dV2_);                                        // V2[:, :L] = V1[:, :L]
@@ -159,6 +161,7 @@ public:
 
     void RR(R* ritzv, std::size_t block) override
     {
+        CHASE_PHASE(this->ctx_, "RR");
         this->flush_swaps(); this->sync_comm();
         const std::size_t n = 2 * block, c0 = this->locked_, m = this->m_, nl = this->n_;
         T* V1 = this->dV1_ + c0 * m;
@@ -191,6 +194,7 @@ public:
 
     void Lanczos(std::size_t m, R* upperb) override
     {
+        CHASE_PHASE(this->ctx_, "Lanczos");
         this->lanczosIter_ = m; this->numLanczos_ = 1;
         std::vector<R> theta(m), tau(m), z(m * m);
         pseudo_lanczos(m, 1, false, theta.data(), tau.data(), z.data());
@@ -198,6 +202,7 @@ public:
     }
     void Lanczos(std::size_t M, std::size_t numvec, R* upperb, R* ritzv, R* Tau, R* ritzV) override
     {
+        CHASE_PHASE(this->ctx_, "Lanczos");
         this->lanczosIter_ = M; this->numLanczos_ = numvec;
         pseudo_lanczos(M, numvec, true, ritzv, Tau, ritzV);
         if (upperb) *upperb = ritzv[M - 1];                   // mpi/pseudo_hermitian_lanczos.hpp:295

@@ -13,6 +13,7 @@
 #include "pchase_hip_impl.hpp"
 #include "chase_hip_pseudo_impl.hpp"
 #include "pchase_hip_pseudo_impl.hpp"
+#include "tape.hpp"
 
 namespace chase_hip { int set_error(int code, const char* what); }
 using namespace chase_amd;
@@ -28,6 +29,8 @@ struct chase_hip_solver {
     SolveStats stats;
     CallTrace trace;
     std::string trace_text;
+    int tape_mode = 0;                              // 0 off, 1 record, 2 replay (tape.hpp)
+    ScalarTape tape;
 };
 
 namespace {
@@ -229,6 +232,9 @@ int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* out)
         else if (name == "hemm_calls") *out = (double)s->ex->hemm_calls();
         else if (name == "hemm_reused_vecs") *out = (double)s->ex->hemm_reused_vecs();
         else if (name == "resd_rechecked") *out = (double)s->ex->resd_rechecked();
+        else if (name == "tape_qr_mismatches") *out = (double)s->tape.qr_variant_mismatches;   // of the last replay
+        else if (name == "tape_position") *out = (double)s->tape.pos;
+        else if (name == "tape_size") *out = (double)s->tape.data.size();
         else if (name == "iterations") *out = (double)s->stats.iterations;          // of the last solve
         else if (name == "filtered_vecs") *out = (double)s->stats.filtered_vecs;
         else rc = chase_hip::set_error(CHASE_HIP_EINVAL, "solver_get: unknown key");
@@ -253,13 +259,49 @@ int chase_hip_solver_solve(chase_hip_solver* s, int record_trace)
     return guarded("solve", [&] {
         // chase::Solve / chase::Solve_pseudo (algorithm/algorithm.hpp:345-364)
         if (s->pseudo) {
+            if (s->tape_mode) throw std::invalid_argument("the pseudo-Hermitian driver is not taped");
             if (s->cplx) Algorithm<zc, ChaseBase<zc>>::solve_pseudo(s->z.get(), &s->stats, &s->trace);
             else Algorithm<double, ChaseBase<double>>::solve_pseudo(s->d.get(), &s->stats, &s->trace);
+        } else if (s->tape_mode) {
+            // the unmodified driver on the taping decorator: record the kernel's host outputs, or replay recorded ones
+            if (s->cplx) {
+                TapeKernel<zc> tk(s->z.get(), s->ex, &s->tape, (TapeKernel<zc>::Mode)s->tape_mode);
+                Algorithm<zc, ChaseBase<zc>>::solve(&tk, &s->stats, &s->trace);
+            } else {
+                TapeKernel<double> tk(s->d.get(), s->ex, &s->tape, (TapeKernel<double>::Mode)s->tape_mode);
+                Algorithm<double, ChaseBase<double>>::solve(&tk, &s->stats, &s->trace);
+            }
         } else {
             if (s->cplx) Algorithm<zc, ChaseBase<zc>>::solve(s->z.get(), &s->stats, &s->trace);
             else Algorithm<double, ChaseBase<double>>::solve(s->d.get(), &s->stats, &s->trace);
         }
     });
+}
+
+/* Scalar tape of chase_hip_solver_solve (chase_amd/host/tape.hpp): mode 1 = the next solves RECORD everything the kernel
+ * tells the driver (Ritz values, residuals, Lanczos outputs, the QR variant taken), mode 2 = the next solves REPLAY the loaded
+ * tape: the kernel does all of its device work, the driver sees the recorded numbers and therefore issues the recorded call
+ * sequence; 0 = off.  Hermitian solves only. */
+int chase_hip_solver_tape_mode(chase_hip_solver* s, int mode)
+{
+    if (!s || mode < 0 || mode > 2) return chase_hip::set_error(CHASE_HIP_EINVAL, "tape_mode: 0, 1 or 2");
+    if (mode && s->pseudo) return chase_hip::set_error(CHASE_HIP_EINVAL, "tape_mode: the pseudo-Hermitian driver is not taped");
+    s->tape_mode = mode;
+    return 0;
+}
+int chase_hip_solver_tape_data(chase_hip_solver* s, const double** data, size_t* count)
+{
+    if (!s || !data || !count) return chase_hip::set_error(CHASE_HIP_EINVAL, "tape_data: NULL argument");
+    *data = s->tape.data.data();
+    *count = s->tape.data.size();
+    return 0;
+}
+int chase_hip_solver_tape_load(chase_hip_solver* s, const double* data, size_t count)
+{
+    if (!s || (!data && count)) return chase_hip::set_error(CHASE_HIP_EINVAL, "tape_load: NULL argument");
+    s->tape.data.assign(data, data + count);
+    s->tape.rewind();
+    return 0;
 }
 
 /* Algorithm<T>::lanczos_for_H2 (algorithm/algorithm.inc:1217-1373) on a pseudo-Hermitian solver: DoS estimates of the

@@ -40,6 +40,12 @@ int chase_hip_ctx_create(chase_hip_ctx** out, int device, void* stream);
 int chase_hip_ctx_destroy(chase_hip_ctx* ctx);
 int chase_hip_ctx_sync(chase_hip_ctx* ctx);
 void* chase_hip_ctx_stream(chase_hip_ctx* ctx);
+/* Operator log: with on != 0 every C-ABI operator this context executes afterwards is listed as one line "name a b c d" (its
+ * name and shapes; no pointers, no scalars), '\n'-separated in chase_hip_ctx_oplog_text; on == 0 stops listing.  The launches
+ * inside the projected eigensolver depend on the data (deflation) and are not listed, only "heevd n".  What the single-rank
+ * replay of a multi-GPU solve is compared with, launch for launch (bench.py --replay-rank, tests/test_gpu_replay.py). */
+int chase_hip_ctx_oplog(chase_hip_ctx* ctx, int on);
+const char* chase_hip_ctx_oplog_text(chase_hip_ctx* ctx);
 const char* chase_hip_last_error(void);
 /* name may be NULL.  clock_khz is the reported max engine clock. */
 int chase_hip_device_info(chase_hip_ctx* ctx, int* num_cu, int* clock_khz, size_t* hbm_bytes, char* name,
@@ -70,16 +76,16 @@ int chase_hip_gemm_d(chase_hip_ctx* ctx, char opA, int m, int n, int k, double a
 int chase_hip_gemm_z(chase_hip_ctx* ctx, char opA, int m, int n, int k, const double alpha[2], const void* A,
                      long lda, const void* B, long ldb, const double beta[2], void* C, long ldc);
 
+/* bytes of split-K workspace a product of this shape uses on a device with num_cu compute units (context-owned, grown on
+ * demand; min_rounds as in chase_hip_ctx_set_gemm_min_rounds) - a pure function of the shape, so that the decomposition and
+ * with it the summation order never depend on allocation history.  Host-only: callable without a GPU. */
+size_t chase_hip_gemm_workspace_bytes(int cplx, char opA, int m, int n, int k, int num_cu, int min_rounds);
 /* 1 when complex products issued in phase 1 (chase_hip_ctx_set_phase: the Chebyshev filter) and phase 2 (the H-times-block
  * products of Rayleigh-Ritz / residuals; CHASE_HIP_GEMM3M_RR=0 keeps those on four) use the three-multiplication scheme
  * (default; CHASE_HIP_GEMM3M=0 or chase_hip_set_gemm3m(0) selects the four-multiplication kernel, the arithmetic of the
  * reference's zgemm).  It applies to launches with m a multiple of 128, k a multiple of 8 and 16-byte addressable
  * operands; other shapes, and every other product (Gram matrices, back-transforms, QR, phase 3), take the
  * four-multiplication kernel. */
-/* bytes of split-K workspace a product of this shape uses on a device with num_cu compute units (context-owned, grown on
- * demand; min_rounds as in chase_hip_ctx_set_gemm_min_rounds) - a pure function of the shape, so that the decomposition and
- * with it the summation order never depend on allocation history.  Host-only: callable without a GPU. */
-size_t chase_hip_gemm_workspace_bytes(int cplx, char opA, int m, int n, int k, int num_cu, int min_rounds);
 int chase_hip_gemm3m_enabled(void);
 int chase_hip_set_gemm3m(int on); /* process-wide run-time switch */
 /* GEMM books of a context, per phase (0 other, 1 filter, 2 H-times-block outside the filter, 3 verification): flops in the reference's
@@ -179,6 +185,11 @@ int chase_hip_conj(chase_hip_ctx* ctx, int m, int n, void* X, long ldx);
  * V == NULL gives plain column norms.  Replaces cuda/residuals.cu:113-296, cpu/residuals.hpp:72-79 */
 int chase_hip_resid_norms(chase_hip_ctx* ctx, int cplx, int m, int n, const void* W, long ldw, const void* V, long ldv,
                           const double* lambda_host, double* resid_host, int squared);
+
+/* the same, result left in device memory (out_dev: n doubles) - no host round trip before the distributed all-reduce
+ * (linalg/internal/nccl/residuals.hpp:28-88) */
+int chase_hip_resid_norms_dev(chase_hip_ctx* ctx, int cplx, int m, int n, const void* W, long ldw, const void* V, long ldv,
+                              const double* lambda_host, double* out_dev, int squared);
 
 /* ---- Cholesky-QR building blocks (replace cublasTsyherk / cusolverDnTpotrf / cublasTtrsm, cuda/cholqr.hpp:110-132) */
 int chase_hip_herk(chase_hip_ctx* ctx, int cplx, int n, int k, const void* V, long ldv, void* A, long lda);

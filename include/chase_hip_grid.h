@@ -38,7 +38,18 @@ int chase_hip_grid_create_rccl(chase_hip_grid** out, chase_hip_ctx* ctx, int npr
                                const char id_col[CHASE_HIP_UNIQUE_ID_BYTES]);
 int chase_hip_grid_create_host(chase_hip_grid** out, chase_hip_ctx* ctx, int nprow, int npcol, int rank,
                                chase_hip_host_allreduce_fn allreduce, chase_hip_host_bcast_fn bcast, void* user);
+/* ONE rank of an nprow x npcol grid with nobody on the other side: all-reduce / broadcast / send-recv keep the stream
+ * ordering, events and waits of the RCCL transport (communication streams, per-panel slots, exposed-wait brackets) and move
+ * nothing (CHASE_HIP_LOOPBACK_TOUCH=1: one read + write pass over the payload on the communication stream - the HBM traffic
+ * a ring all-reduce causes on this device); agree_max keeps the caller's value.  For the single-rank REPLAY of a multi-GPU
+ * solve (bench.py --replay-rank 4x2): results are wrong by construction, the compute side's time is right. */
+int chase_hip_grid_create_loopback(chase_hip_grid** out, chase_hip_ctx* ctx, int nprow, int npcol, int rank);
 int chase_hip_grid_destroy(chase_hip_grid* g);
+/* communication streams: 2 (default) = one per group - on a 4 x 2 grid the row and column communicators use disjoint xGMI
+ * links, so their collectives do not queue behind each other; 1 = both groups on one stream (CHASE_HIP_COMM_STREAMS=1).
+ * Callable between collectives (it synchronises the communication streams). */
+int chase_hip_grid_set_comm_streams(chase_hip_grid* g, int n);
+int chase_hip_grid_comm_streams(chase_hip_grid* g);
 int chase_hip_grid_info(chase_hip_grid* g, int* nprow, int* npcol, int* myrow, int* mycol);
 /* 1 if collectives in `group` really communicate (group size > 1, or CHASE_HIP_RCCL_FORCE set: size-1 groups are then
  * run through RCCL as well so that a single-GPU box exercises ncclCommInitRank / ncclAllReduce / the stream logic) */
@@ -50,8 +61,9 @@ int chase_hip_grid_allreduce(chase_hip_grid* g, int group, void* dev, size_t cou
 int chase_hip_grid_bcast(chase_hip_grid* g, int group, void* dev, size_t count, int root, int async);
 int chase_hip_grid_wait(chase_hip_grid* g); /* context stream waits for all collectives issued so far */
 /* per-slot events for pipelining: record on the communication stream / make the context stream wait for a slot */
-int chase_hip_grid_event_record(chase_hip_grid* g, int slot);
-int chase_hip_grid_event_wait(chase_hip_grid* g, int slot);
+int chase_hip_grid_event_record(chase_hip_grid* g, int slot);                /* on every communication stream */
+int chase_hip_grid_event_record_on(chase_hip_grid* g, int group, int slot);  /* on the stream of `group`'s collectives */
+int chase_hip_grid_event_wait(chase_hip_grid* g, int slot);                  /* last record of the slot on every stream */
 /* all ranks agree on the maximum of a host integer (control-flow decisions such as the potrf info) */
 int chase_hip_grid_agree_max(chase_hip_grid* g, int* value);
 /* point-to-point exchange of device doubles inside `group` — replaces ncclSendrecvWrapper / MPI_Sendrecv
@@ -66,7 +78,7 @@ int chase_hip_grid_set_host_sendrecv(chase_hip_grid* g, chase_hip_host_sendrecv_
  * else to run (synchronises the context stream), and the number of waits */
 int chase_hip_grid_set_profiling(chase_hip_grid* g, int on);
 int chase_hip_grid_comm_exposed_ms(chase_hip_grid* g, double* ms, unsigned long long* waits, int reset);
-/* which transport the grid runs on and how many ranks RCCL itself reports for this rank's row / column communicator
+/* which transport the grid runs on (*is_rccl: 0 host callbacks, 1 RCCL, 2 loopback) and how many ranks RCCL itself reports for this rank's row / column communicator
  * (ncclCommCount; 1 for a group without communicator) */
 int chase_hip_grid_transport(chase_hip_grid* g, int* is_rccl, int* row_ranks, int* col_ranks);
 

@@ -63,6 +63,18 @@ int chase_hip_solver_solve(chase_hip_solver* s, int record_trace);
 typedef int (*chase_hip_iteration_fn)(void* user, size_t iteration, size_t filtered_vecs, size_t locked,
                                       size_t unconverged);
 int chase_hip_solver_set_iteration_hook(chase_hip_solver* s, chase_hip_iteration_fn fn, void* user);
+/* Scalar tape (chase_amd/host/tape.hpp).  The driver of chase_hip_solver_solve (algorithm/algorithm.inc:1376-1788) steers a
+ * solve only by the host-visible numbers the Impl returns: Ritz values (RR), residuals (Resd), the Lanczos outputs.  mode 1:
+ * the next solves record them (plus the QR variant each QR took and the number of residuals re-taken on the tolerance);
+ * mode 2: the next solves replay a loaded tape - the Impl executes every operator at ITS shapes, the driver is shown the
+ * recorded numbers and so issues exactly the recorded call sequence; 0: off.  With a loopback grid
+ * (chase_hip_grid_create_loopback) this measures ONE rank of a multi-GPU solve on a one-GPU box (bench.py --replay-rank).
+ * get keys after a replay: tape_qr_mismatches (QR calls that took another variant than recorded), tape_position, tape_size.
+ * Hermitian solves only.  The data pointer stays valid until the next solve / load on this solver. */
+int chase_hip_solver_tape_mode(chase_hip_solver* s, int mode);
+int chase_hip_solver_tape_data(chase_hip_solver* s, const double** data, size_t* count);
+int chase_hip_solver_tape_load(chase_hip_solver* s, const double* data, size_t count);
+
 /* Algorithm<T>::lanczos_for_H2 (algorithm/algorithm.inc:1217-1373; tests/algorithm/lanczos_for_H2_test.cpp) on a
  * pseudo-Hermitian solver: DoS-based estimates of the H^2 spectrum go to the solver's ritzv[0 .. nev+nex), *upperb = b_sup,
  * *idx = number of Ritz directions moved into the start block */
