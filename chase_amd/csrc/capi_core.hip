@@ -112,6 +112,14 @@ int chase_hip_ctx_oplog(chase_hip_ctx* c, int on)
     c->oplog_on = on != 0;
     return 0;
 }
+/* delta > 0: operators executed from now on are not listed (nestable), delta < 0: listed again */
+int chase_hip_ctx_oplog_mute(chase_hip_ctx* c, int delta)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "ctx == NULL");
+    c->oplog_mute += delta;
+    if (c->oplog_mute < 0) c->oplog_mute = 0;
+    return 0;
+}
 const char* chase_hip_ctx_oplog_text(chase_hip_ctx* c)
 {
     if (!c) return "";

@@ -25,6 +25,11 @@ struct HipImplExtras {
     // k >= 0: the next Resd re-takes the residuals of its first k columns from a fresh four-product H v whatever their
     // values (single-rank replay: as many as the recorded solve re-took on the tolerance, tape.hpp); -1: by value (default)
     virtual void set_forced_recheck(long) {}
+    // v >= 0: the next QR takes variant v (0 Householder, 1/2/3 CholQR1 / CholQR2 / shifted CholQR2) whatever its data say -
+    // a Cholesky factorisation that fails on the replayed rank's numbers is retried on a shifted Gram matrix instead of
+    // falling back to Householder (single-rank replay follows the recording's QR variants, tape.hpp); -1: by data (default)
+    virtual void set_forced_qr(int) {}
+    virtual std::size_t forced_qr_retries() const { return 0; }
     // phase marker of the profiler ranges (CHASE_HIP_ROCTX=1, roctx.hpp): nothing to implement
 };
 

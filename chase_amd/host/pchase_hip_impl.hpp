@@ -313,7 +313,10 @@ public:
         R thld_hi = 1e8, thld_lo = 2e1;
         if (const char* s = std::getenv("CHASE_CHOLQR1_THLD")) thld_lo = std::atof(s);
         last_qr_variant_ = 0;
-        if (disable == 1 && cond != (R)1.0) {
+        if (forced_qr_ >= 0) {                                  // single-rank replay: the recording's variant (set_forced_qr)
+            if (forced_qr_ == 0) householder();
+            else { last_qr_variant_ = forced_qr_; cholqr_dist(forced_qr_); }
+        } else if (disable == 1 && cond != (R)1.0) {
             householder();
         } else {
             const int variant = (cond > thld_hi) ? 3 : (cond < thld_lo ? 1 : 2);
@@ -478,6 +481,8 @@ public:
         sum_resid_squares(dW1_ + c0 * n_, dW2_ + c0 * n_, lambda, out, cnt);
     }
     void set_forced_recheck(long k) override { forced_recheck_ = k; }
+    void set_forced_qr(int v) override { forced_qr_ = v; }
+    std::size_t forced_qr_retries() const override { return forced_qr_retries_; }
     std::size_t resd_rechecked() const override { return resd_rechecked_; }
 
     // the reference's residual step as it stands (mpi/residuals.hpp:61-107: H V, column -> row redistribution of V, local
@@ -745,6 +750,23 @@ protected:
             info = chase_hip_potrf_upper(ctx_, CP, n, dA_, (long)n);
             hip_ok(info, "potrf");
             coll(chase_hip_grid_agree_max(grid_, &info));
+            if (info != 0 && forced_qr_ > 0) {
+                // replay only: the lone rank's numbers failed a factorisation the recorded solve got through - same passes,
+                // same shapes, on a Gram matrix (still packed in dPack_) shifted until it factorises
+                // (kept out of the operator log: the real rank has no such retries, everything around them is compared)
+                struct Mute { chase_hip_ctx* c; Mute(chase_hip_ctx* x) : c(x) { chase_hip_ctx_oplog_mute(c, 1); } ~Mute() { chase_hip_ctx_oplog_mute(c, -1); } } mute(ctx_);
+                double nrmf = 0, boost = 1.0;
+                for (int tries = 0; tries < 12 && info != 0; ++tries, boost *= 1e3) {
+                    hip_ok(chase_hip_unpack_upper(ctx_, CP, n, dPack_, dA_, (long)n, 1), "unpack_upper");
+                    hip_ok(chase_hip_abs_trace(ctx_, CP, n, dA_, (long)n, &nrmf), "abs_trace");
+                    if (!(nrmf > 0) || !std::isfinite(nrmf)) nrmf = 1.0;
+                    hip_ok(chase_hip_shift_diag(ctx_, CP, n, dA_, (long)n, boost * 1e-10 * nrmf), "shift");
+                    info = chase_hip_potrf_upper(ctx_, CP, n, dA_, (long)n);
+                    hip_ok(info, "potrf");
+                    ++forced_qr_retries_;
+                }
+                if (info != 0) throw std::runtime_error("pChaseHip: replayed Gram matrix does not factorise even when shifted");
+            }
             if (ps == 0 && info != 0) return info;
             hip_ok(chase_hip_trsm_right_upper(ctx_, CP, (int)m_, n, dA_, (long)n, dV1_, (long)m_), "trsm");
         }
@@ -893,6 +915,7 @@ protected:
     T* dW3_ = nullptr;
     T* dChk_ = nullptr; std::size_t chk_cols_ = 0, resd_rechecked_ = 0;   // scratch of recheck_borderline
     long forced_recheck_ = -1;                                            // set_forced_recheck (single-rank replay)
+    int forced_qr_ = -1; std::size_t forced_qr_retries_ = 0;              // set_forced_qr (single-rank replay)
     R norm_h_ = 0;                                                        // Lanczos upper bound of the last solve (recheck window)
     bool loopback_ = false; std::size_t stage_rows_ = 0;
     T *dV1_ = nullptr, *dV2_ = nullptr, *dVt_ = nullptr, *dW1_ = nullptr, *dW2_ = nullptr, *dA_ = nullptr;

@@ -233,6 +233,7 @@ int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* out)
         else if (name == "hemm_reused_vecs") *out = (double)s->ex->hemm_reused_vecs();
         else if (name == "resd_rechecked") *out = (double)s->ex->resd_rechecked();
         else if (name == "tape_qr_mismatches") *out = (double)s->tape.qr_variant_mismatches;   // of the last replay
+        else if (name == "tape_qr_retries") *out = (double)s->ex->forced_qr_retries();   // shifted re-factorisations, replay
         else if (name == "tape_position") *out = (double)s->tape.pos;
         else if (name == "tape_size") *out = (double)s->tape.data.size();
         else if (name == "iterations") *out = (double)s->stats.iterations;          // of the last solve

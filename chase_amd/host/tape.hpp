@@ -65,7 +65,7 @@ public:
         if (mode == RECORD) { tape->data.clear(); tape->rewind(); }
         else tape->rewind();
     }
-    ~TapeKernel() override { if (ex_) ex_->set_forced_recheck(-1); }
+    ~TapeKernel() override { if (ex_) { ex_->set_forced_recheck(-1); ex_->set_forced_qr(-1); } }
 
     // ---- the calls whose host outputs steer the driver ------------------------------------------------------------------
     void RR(R* ritzv, std::size_t block) override
@@ -120,10 +120,21 @@ public:
     }
     void QR(std::size_t fixednev, R cond) override
     {
+        if (mode_ == REPLAY) {
+            // the replayed kernel takes the variant the recording took (its own numbers might fail a Cholesky factorisation
+            // the real rank's did not, or the other way round); what it then reports must be that variant
+            const double want = *tape_->take(ScalarTape::QR, 1);
+            if (ex_ && want >= 0) ex_->set_forced_qr((int)want);
+            k_->QR(fixednev, cond);
+            if (ex_) {
+                ex_->set_forced_qr(-1);
+                if ((double)ex_->last_qr_variant() != want) ++tape_->qr_variant_mismatches;
+            }
+            return;
+        }
         k_->QR(fixednev, cond);
         double variant = ex_ ? (double)ex_->last_qr_variant() : -1.0;
-        if (mode_ == RECORD) tape_->put(ScalarTape::QR, &variant, 1);
-        else if (*tape_->take(ScalarTape::QR, 1) != variant) ++tape_->qr_variant_mismatches;   // e.g. potrf failed on replayed data
+        tape_->put(ScalarTape::QR, &variant, 1);
     }
     void Lock(std::size_t n) override { locked_ += n; k_->Lock(n); }
     void Start() override { locked_ = 0; k_->Start(); }

@@ -121,6 +121,7 @@ def replay_rank(ctx, tape, meta, nprow, npcol, rank=0, block_cyclic=None, oplog=
            "filter_tflops_executed_this_rank": books["filter"]["executed_flops"] / filt_s / 1e12 if filt_s > 0 else None,
            "iterations": st["iterations"], "filtered_vecs": st["filtered_vecs"], "locked": st["locked"],
            "call_sequence_equals_recording": bool(ok), "qr_variant_mismatches": int(s.get("tape_qr_mismatches")),
+           "qr_shifted_refactorisations_on_replayed_numbers": int(s.get("tape_qr_retries")),
            "residuals_rechecked": int(s.get("resd_rechecked")),
            "waits_on_communication_streams": int(waits), "exposed_ms_of_those_waits_with_nothing_on_the_wire": exposed_ms,
            "gemm_books": books, "per_iteration": per_iter,

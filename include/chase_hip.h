@@ -45,6 +45,7 @@ void* chase_hip_ctx_stream(chase_hip_ctx* ctx);
  * inside the projected eigensolver depend on the data (deflation) and are not listed, only "heevd n".  What the single-rank
  * replay of a multi-GPU solve is compared with, launch for launch (bench.py --replay-rank, tests/test_gpu_replay.py). */
 int chase_hip_ctx_oplog(chase_hip_ctx* ctx, int on);
+int chase_hip_ctx_oplog_mute(chase_hip_ctx* ctx, int delta); /* > 0: stop listing (nestable), < 0: resume */
 const char* chase_hip_ctx_oplog_text(chase_hip_ctx* ctx);
 const char* chase_hip_last_error(void);
 /* name may be NULL.  clock_khz is the reported max engine clock. */

@@ -80,7 +80,7 @@ def test_replayed_rank_issues_the_real_ranks_launch_list(ctx, grid, N, nev, nex,
     for r in range(1, nprow * npcol):
         assert np.array_equal(real[r]["tape"], real[0]["tape"])
     lam_exact = -N + 2.0 * np.arange(nev)
-    assert np.max(np.abs(real[0]["lam"] - lam_exact)) < 1e-6
+    assert np.max(np.abs(real[0]["lam"] - lam_exact)) < 1e-4      # (the test matrix carries a 1e-6 perturbation)
     H = O.clement(N, cplx)
     rl, cl = cd.Layout(N, mb, nprow), cd.Layout(N, mb, npcol)
     for r in range(nprow * npcol):
