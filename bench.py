@@ -712,6 +712,9 @@ def main():
                     help="how the ranks of a multi-GPU run hold their devices: processes (= bound: one process per GPU, one "
                          "visible device each), unbound (all devices visible), threads (one process, one thread per GPU), "
                          "auto (default): the first of bound / unbound / threads whose transport probe passes")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="multi-GPU runs: keep the default panel width / K-piece granularity / communication streams instead "
+                         "of measuring them before the first solve (chase_amd/autotune.py)")
     ap.add_argument("--replay-rank", default=None, metavar="GRIDS",
                     help="single-rank replay (chase_amd/replay.py): e.g. 4x2 or 4x2,2x2,2x1 - ONE rank of each grid is driven "
                          "through the taped call sequence of a real single-GPU solve of the workload on a loopback grid (no "

@@ -1,0 +1,121 @@
+"""First-contact self-tuning of the panel pipeline (bench.py --gpus N, N >= 2).
+
+Three run-time knobs of the distributed HEMM cannot be tuned without the hardware the job runs on - no session of this build
+has ever had two GPUs -: the column-panel width of the pipeline (how much of a product's all-reduce can hide behind the next
+panel's GEMM against how well a panel fills the chip), the K-piece granularity of products that share the chip with a
+collective (CHASE_HIP_PANEL_ROUNDS: what the CUs RCCL's kernels take displace), and whether the row and column communicators
+get one communication stream each or share one.  So the first thing a multi-GPU run does with them is MEASURE: in the untimed
+warm-up, before its first solve, every candidate setting runs the same few full-width filter steps (both directions of the
+distributed HEMM, all-reduces included, linalg/internal/nccl/hemm.hpp:25-399 is the reference's counterpart), one factor at a
+time; the fastest setting (max over ranks; exposed communication breaks ties) is locked for everything that follows and the
+whole table goes into the JSON line (`autotune`).  In-process setters only (chase_hip_solver_set "panel_cols" /
+"panel_rounds", chase_hip_grid_set_comm_streams): no restart, no re-exec.  Every rank applies the same candidate at the same
+point of its call sequence and all ranks take the decision from the same agreed numbers, so the collectives stay matched.
+
+Why not "one setting per warm-up ITERATION of a solve": the iterations of a solve are not equal work (widths shrink as columns
+retire, iteration 0 carries Lanczos and the first QR), so their seconds would compare settings on different workloads; the
+trial steps here are identical for every candidate.  The knobs can still be switched between the iterations of a solve
+(tests/dist_scenarios.py scenario_knob_switching)."""
+
+PANELS = (128, 256, 512)
+TIE = 0.01                      # relative margin inside which two settings count as equally fast
+
+
+def plan(base, budget):
+    """One-factor-at-a-time schedule as a list of stages; a stage is (knob, [values to try]); the base value of a knob is always
+    measured (first trial overall, then implicitly as the incumbent).  budget = number of trials the caller can afford."""
+    stages = [("panel_cols", [p for p in PANELS if p != base["panel_cols"]]),
+              ("panel_rounds", [0 if base["panel_rounds"] else 4]),
+              ("comm_streams", [1 if base["comm_streams"] == 2 else 2])]
+    out, left = [], budget - 1                # one trial is the base setting itself
+    for knob, values in stages:
+        take = values[:max(left, 0)]
+        if take:
+            out.append((knob, take))
+            left -= len(take)
+    return out
+
+
+def better(a, b):
+    """a, b: trial records {"seconds", "exposed_ms"}: is a strictly preferable to b?  Faster by more than the tie margin wins;
+    inside the margin the one with less exposed communication wins; equal on both, the incumbent (b) stays."""
+    if a["seconds"] < b["seconds"] * (1.0 - TIE):
+        return True
+    if a["seconds"] > b["seconds"] * (1.0 + TIE):
+        return False
+    return a["exposed_ms"] < b["exposed_ms"] * (1.0 - TIE) and a["seconds"] <= b["seconds"] * (1.0 + TIE)
+
+
+def tune(base, budget, measure):
+    """measure(setting) -> {"seconds", "exposed_ms"} (already agreed between the ranks).  Returns (best setting, table)."""
+    best = dict(base)
+    rec = measure(best)
+    table = [dict(setting=dict(best), **rec, kept=True)]
+    best_rec = rec
+    if budget < 2:
+        return best, table
+    for knob, values in plan(base, budget):
+        for v in values:
+            cand = dict(best)
+            cand[knob] = v
+            rec = measure(cand)
+            keep = better(rec, best_rec)
+            table.append(dict(setting=dict(cand), **rec, kept=keep))
+            if keep:
+                for row in table[:-1]:
+                    row["kept"] = False
+                best, best_rec = cand, rec
+    return best, table
+
+
+def apply_setting(s, grid, setting):
+    """collective: every rank calls it with the same setting at the same point"""
+    s.set(panel_cols=setting["panel_cols"], panel_rounds=setting["panel_rounds"])
+    grid.set_comm_streams(setting["comm_streams"])
+
+
+def current_setting(s, grid):
+    return {"panel_cols": int(s.get("panel_cols")), "panel_rounds": int(s.get("panel_rounds")),
+            "comm_streams": int(grid.comm_streams())}
+
+
+def first_contact(s, ctx, grid, comm, nevex, budget=5, steps=2, log=None):
+    """Runs the schedule on an initialised distributed solver BEFORE its first solve; leaves the best setting applied.
+    A trial = `steps` pairs of full-width filter products (column -> row and row -> column, all-reduces included) between two
+    (device sync + barrier) brackets; seconds = max over ranks."""
+    import time
+    from .capi import lib, check
+
+    def measure(setting):
+        apply_setting(s, grid, setting)
+        s.Start()
+        s.initVecs(True)
+        check(lib.chase_hip_ctx_set_phase(ctx.h, 1), "set_phase")
+        try:
+            s.HEMM(nevex, 0.01, 0.0, 0)                    # untimed pair: first touch of this decomposition
+            s.HEMM(nevex, 0.01, -0.5, 0)
+            check(lib.chase_hip_grid_wait(grid.h), "grid_wait")
+            ctx.sync()
+            e0, _ = grid.comm_exposed_ms()
+            comm.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                s.HEMM(nevex, 0.01, -0.5, 0)
+                s.HEMM(nevex, 0.01, -0.5, 0)
+            check(lib.chase_hip_grid_wait(grid.h), "grid_wait")
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            e1, _ = grid.comm_exposed_ms()
+        finally:
+            check(lib.chase_hip_ctx_set_phase(ctx.h, 0), "set_phase")
+        sec, exp = comm.allreduce_max([dt, e1 - e0])
+        rec = {"seconds": sec / (2 * steps), "exposed_ms": exp / (2 * steps)}
+        if log:
+            log(f"autotune: {setting} -> {rec['seconds'] * 1e3:.1f} ms per full-width product, {rec['exposed_ms']:.1f} ms exposed")
+        return rec
+
+    base = current_setting(s, grid)
+    best, table = tune(base, budget, measure)
+    apply_setting(s, grid, best)
+    return {"base": base, "chosen": best, "unit": "seconds per full-width distributed HEMM (max over ranks), one factor at a time",
+            "trials": table}

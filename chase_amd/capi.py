@@ -324,6 +324,11 @@ _sig("chase_hip_op_lock", c_int, c_void_p, c_size_t)
 _sig("chase_hip_op_lanczos", c_int, c_void_p, c_size_t, c_size_t, P(c_double), c_void_p, c_void_p, c_void_p)
 _sig("chase_hip_op_lanczos_dos", c_int, c_void_p, c_size_t, c_size_t, c_void_p)
 _sig("chase_hip_op_check_symmetry", c_int, c_void_p, P(c_int))
+_sig("chase_hip_op_sym_or_herm", c_int, c_void_p, c_char)
+_sig("chase_hip_cols_indexed", c_int, c_void_p, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_int)
+_sig("chase_hip_tri_mask_bc", c_int, c_void_p, c_int, c_char, c_int, c_int, c_void_p, c_long, c_long, c_int, c_int, c_long, c_int,
+     c_int)
+_sig("chase_hip_conj_transpose_add", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long)
 
 
 def set_iteration_hook(solver, fn):
@@ -486,6 +491,9 @@ class Solver:
         f = c_int()
         check(lib.chase_hip_op_check_symmetry(self.h, C.byref(f)), "checkSymmetryEasy")
         return bool(f.value)
+
+    def symOrHermMatrix(self, uplo):
+        check(lib.chase_hip_op_sym_or_herm(self.h, uplo.encode()[0:1]), "symOrHermMatrix")
 
 
 _sig("chase_hip_solver_create_pseudo", c_int, P(c_void_p), c_void_p, c_int, c_size_t, c_size_t, c_size_t, c_void_p,

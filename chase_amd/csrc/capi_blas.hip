@@ -140,6 +140,57 @@ int chase_hip_rows_indexed(chase_hip_ctx* c, int cplx, const void* in, long ld_i
 /* local shard (mloc x nloc) of the N x N Clement-type test matrix.  Rows: global = roff + ((l / mb) * pr + pi) * mb +
  * l % mb; columns likewise with (nb, pc, pj, coff).  Whole matrix on one GPU: mb = nb = N, pr = pc = 1, rest 0.
  * H = scale * (Clement + perturb * Hermitian N(0,1)); perturb = 0 gives the unperturbed tridiagonal matrix. */
+/* out[:, c] = in[:, idx[c]], c < ncols (idx on the device): column gather, the counterpart of chase_hip_rows_indexed */
+int chase_hip_cols_indexed(chase_hip_ctx* c, int cplx, int m, const void* in, long ld_in, void* out, long ld_out,
+                           const int* idx_dev, int ncols)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "cols_indexed: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("cols_indexed", m, ncols, 0, 0);
+    if (m < 0 || ncols < 0 || ld_in < m || ld_out < m) return set_error(CHASE_HIP_EINVAL, "cols_indexed: bad shape");
+    if (m == 0 || ncols == 0) return 0;
+    if (!in || !out || !idx_dev) return set_error(CHASE_HIP_EINVAL, "cols_indexed: NULL argument");
+    const int e = ept_of(cplx);
+    KCHK(copy_cols_indexed_range(c->stream, (const double*)in, ld_in * e, (double*)out, ld_out * e, (long)m * e, idx_dev, 0, ncols),
+         "cols_indexed");
+    return 0;
+}
+
+/* Triangle mask of a block-cyclic shard: entries of the triangle that is not kept (uplo 'U': the strictly lower one, 'L': the
+ * strictly upper one, by GLOBAL position) become 0, diagonal entries are halved - the first step of the distributed
+ * symOrHermMatrix (linalg/internal/mpi/symOrHerm.hpp:138-170,232-296) */
+int chase_hip_tri_mask_bc(chase_hip_ctx* c, int cplx, char uplo, int mloc, int nloc, void* H, long ldh, long mb, int pr, int pi,
+                          long nb, int pc, int pj)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "tri_mask_bc: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("tri_mask_bc", mloc, nloc, uplo, 0);
+    if (uplo != 'U' && uplo != 'L' && uplo != 'u' && uplo != 'l') return set_error(CHASE_HIP_EINVAL, "tri_mask_bc: uplo must be 'U' or 'L'");
+    if (mloc < 0 || nloc < 0 || ldh < mloc || mb <= 0 || nb <= 0 || pr <= 0 || pc <= 0 || pi < 0 || pi >= pr || pj < 0 || pj >= pc)
+        return set_error(CHASE_HIP_EINVAL, "tri_mask_bc: bad shape / layout");
+    if (mloc == 0 || nloc == 0) return 0;
+    if (!H) return set_error(CHASE_HIP_EINVAL, "tri_mask_bc: NULL matrix");
+    KCHK(tri_mask_bc(c->stream, cplx != 0, (double*)H, ldh, mloc, nloc, mb, pr, pi, nb, pc, pj, (uplo == 'U' || uplo == 'u') ? 1 : 0),
+         "tri_mask_bc");
+    return 0;
+}
+
+/* H[colmap[b], rowmap[a]] += conj(P[a, b]), a < nr, b < nc (maps on the device): adds the conjugate transpose of a packed
+ * piece into a shard - replaces the p?tranc + local add of the reference's symOrHermMatrix (mpi/symOrHerm.hpp:176-186) */
+int chase_hip_conj_transpose_add(chase_hip_ctx* c, int cplx, int nr, int nc, const void* P, long ldp, const int* rowmap_dev,
+                                 const int* colmap_dev, void* H, long ldh)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "conj_transpose_add: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("conj_transpose_add", nr, nc, 0, 0);
+    if (nr < 0 || nc < 0 || ldp < nr) return set_error(CHASE_HIP_EINVAL, "conj_transpose_add: bad shape");
+    if (nr == 0 || nc == 0) return 0;
+    if (!P || !H || !rowmap_dev || !colmap_dev) return set_error(CHASE_HIP_EINVAL, "conj_transpose_add: NULL argument");
+    KCHK(conj_transpose_add(c->stream, cplx != 0, (const double*)P, ldp, nr, nc, rowmap_dev, colmap_dev, (double*)H, ldh),
+         "conj_transpose_add");
+    return 0;
+}
+
 int chase_hip_gen_clement(chase_hip_ctx* c, int cplx, void* H, long ldh, int mloc, int nloc, long N, int mb, int pr,
                           int pi, long roff, int nb, int pc, int pj, long coff, double scale, double perturb,
                           unsigned long long seed)

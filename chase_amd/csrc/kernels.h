@@ -35,6 +35,10 @@ int copy2d(hipStream_t st, const double* src, long ld_src_d, double* dst, long l
 int swap_cols(hipStream_t st, double* a, double* b, long md);
 int rows_indexed(hipStream_t st, bool cplx, const double* in, long ld_in, double* out, long ld_out, const int* idx_dev,
                  int np, int ncols, int scatter);
+int tri_mask_bc(hipStream_t st, bool cplx, double* H, long ldh, int mloc, int nloc, long mb, int pr, int pi, long nb, int pc,
+                int pj, int keep_upper);
+int conj_transpose_add(hipStream_t st, bool cplx, const double* P, long ldp, int nr, int nc, const int* rowmap_dev,
+                       const int* colmap_dev, double* H, long ldh);
 int copy_cols_indexed(hipStream_t st, const double* src, long ld_src_d, double* dst, long ld_dst_d, long md,
                       const int* src_idx_dev, const int* dst_idx_dev, int cnt);
 // dst column dst0 + c <- src column src_idx[c], c < cnt (md doubles per column)

@@ -365,6 +365,44 @@ __global__ __launch_bounds__(256) void rows_indexed_kernel(const double* __restr
     }
 }
 
+// Triangle mask of a block-cyclic shard (distributed symOrHermMatrix, linalg/internal/mpi/symOrHerm.hpp:127-320): local entry
+// (il, jl) has the global position (gi, gj) = (block-cyclic row index over pr ranks of block mb, column index over pc ranks of
+// block nb); entries of the triangle that is NOT kept become 0, the diagonal is halved.  keep_upper != 0: gi <= gj is kept.
+template <int EPT>
+__global__ __launch_bounds__(256) void tri_mask_bc_kernel(double* __restrict__ H, long ldh, int mloc, int nloc, long mb, int pr,
+                                                          int pi, long nb, int pc, int pj, int keep_upper)
+{
+    for (int jl = blockIdx.y; jl < nloc; jl += gridDim.y) {
+        const long gj = ((long)(jl / nb) * pc + pj) * nb + jl % nb;
+        for (int il = blockIdx.x * 256 + threadIdx.x; il < mloc; il += gridDim.x * 256) {
+            const long gi = ((long)(il / mb) * pr + pi) * mb + il % mb;
+            double* h = H + ((long)jl * ldh + il) * EPT;
+            if (gi == gj) { h[0] *= 0.5; if (EPT == 2) h[1] *= 0.5; }
+            else if (keep_upper ? (gi > gj) : (gi < gj)) { h[0] = 0.0; if (EPT == 2) h[1] = 0.0; }
+        }
+    }
+}
+
+// H[colmap[b], rowmap[a]] += conj(P[a, b]) for a < nr, b < nc: the conjugate transpose of a packed piece added into a shard
+// whose local rows / columns the maps name (second hop of the distributed symOrHermMatrix).  One thread per element of P,
+// consecutive threads along a (P is read coalesced; the writes of a wave go to one row of H - strided, but this runs once
+// per problem, not per iteration).
+template <int EPT>
+__global__ __launch_bounds__(256) void conj_transpose_add_kernel(const double* __restrict__ P, long ldp, int nr, int nc,
+                                                                 const int* __restrict__ rowmap, const int* __restrict__ colmap,
+                                                                 double* __restrict__ H, long ldh)
+{
+    for (int b = blockIdx.y; b < nc; b += gridDim.y) {
+        const long hr = colmap[b];
+        for (int a = blockIdx.x * 256 + threadIdx.x; a < nr; a += gridDim.x * 256) {
+            const double* p = P + ((long)b * ldp + a) * EPT;
+            double* h = H + ((long)rowmap[a] * ldh + hr) * EPT;
+            h[0] += p[0];
+            if (EPT == 2) h[1] -= p[1];
+        }
+    }
+}
+
 // A[i,j] = conj(A[j,i]) for i < j (rebuild the strictly-upper triangle from the lower one) and Im A[j,j] = 0
 __global__ void mirror_lower_kernel(double* __restrict__ A, long lda, int n, int ept)
 {
@@ -432,6 +470,24 @@ int copy_cols_indexed_range(hipStream_t st, const double* src, long ld_src_d, do
     if (cnt <= 0 || md <= 0) return 0;
     hipLaunchKernelGGL(copy_cols_indexed_kernel, grid2(md, cnt), dim3(256), 0, st, src, ld_src_d, dst + (long)dst0 * ld_dst_d,
                        ld_dst_d, md, src_idx_dev, (const int*)nullptr, cnt);
+    return (int)hipGetLastError();
+}
+int tri_mask_bc(hipStream_t st, bool cplx, double* H, long ldh, int mloc, int nloc, long mb, int pr, int pi, long nb, int pc,
+                int pj, int keep_upper)
+{
+    if (mloc <= 0 || nloc <= 0) return 0;
+    const dim3 g = grid2(mloc, nloc);
+    if (cplx) hipLaunchKernelGGL(tri_mask_bc_kernel<2>, g, dim3(256), 0, st, H, ldh, mloc, nloc, mb, pr, pi, nb, pc, pj, keep_upper);
+    else      hipLaunchKernelGGL(tri_mask_bc_kernel<1>, g, dim3(256), 0, st, H, ldh, mloc, nloc, mb, pr, pi, nb, pc, pj, keep_upper);
+    return (int)hipGetLastError();
+}
+int conj_transpose_add(hipStream_t st, bool cplx, const double* P, long ldp, int nr, int nc, const int* rowmap_dev,
+                       const int* colmap_dev, double* H, long ldh)
+{
+    if (nr <= 0 || nc <= 0) return 0;
+    const dim3 g = grid2(nr, nc);
+    if (cplx) hipLaunchKernelGGL(conj_transpose_add_kernel<2>, g, dim3(256), 0, st, P, ldp, nr, nc, rowmap_dev, colmap_dev, H, ldh);
+    else      hipLaunchKernelGGL(conj_transpose_add_kernel<1>, g, dim3(256), 0, st, P, ldp, nr, nc, rowmap_dev, colmap_dev, H, ldh);
     return (int)hipGetLastError();
 }
 int rows_indexed(hipStream_t st, bool cplx, const double* in, long ld_in, double* out, long ld_out, const int* idx_dev,

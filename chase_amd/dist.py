@@ -336,6 +336,10 @@ class DistSolver:
         check(lib.chase_hip_op_check_symmetry(self.h, C.byref(f)), "checkSymmetryEasy")
         return bool(f.value)
 
+    def symOrHermMatrix(self, uplo):
+        """collective: complete the Hermitian matrix on the device shards from its stored triangle 'U' / 'L'"""
+        check(lib.chase_hip_op_sym_or_herm(self.h, uplo.encode()[0:1]), "symOrHermMatrix")
+
     def Lanczos(self, M, numvec):
         ub = c_double()
         if numvec == 0:                     # single-vector form: upper bound only (interface.hpp Lanczos(m, upperb))

@@ -3,8 +3,8 @@ nprow >= npcol: 2x1, 2x2, 4x2; grid/mpiGrid2D.hpp), RCCL row/column all-reduces 
 single-GPU line (strong scaling).  Two forms: one PROCESS per GPU (run_distributed: torch.distributed / gloo over
 MASTER_ADDR only for bootstrap - unique-id exchange -, barriers and the max / sum over ranks of the timing figures) and one
 THREAD per GPU inside one process (run_threads).  Either way a run first PROVES its transport (transport_proof: bus
-bandwidth of a 256 MB all-reduce per communicator, in the JSON line) and exits non-zero instead of printing a scaling
-number when a communicator is not on xGMI.
+bandwidth of a 256 MB all-reduce per communicator, in the JSON line); a probe child of `--ranks auto` exits with status 5 when
+a communicator is not on xGMI (the next mode is tried), a measured run marks its line scaling_valid = false.
 
 A rank whose communicator cannot be created exits non-zero: there is no fallback transport in a measured run (the
 host-callback transport exists for tests on a single-GPU box: CHASE_HIP_TRANSPORT=host, labelled in config.workload)."""
@@ -76,8 +76,9 @@ def comm_probe(ctx, grid, dH, m_loc, n_loc, cplx, nevex, panel=256, reps=5):
 def transport_proof(ctx, grid, comm, nbytes=256 << 20, reps=3):
     """Before any solve: one 256 MB all-reduce per communicator, timed on its own.  A size >= 2 RCCL group that moves less
     than MIN_BUSBW_GBPS is not running over xGMI peer-to-peer (host-staged rings over PCIe reach 10-25 GB/s, one xGMI link
-    ~50 GB/s per direction and the 7 links of a device several times that) - the run then refuses to print a scaling
-    number.  Returns (record, ok) identical on every rank."""
+    ~50 GB/s per direction and the 7 links of a device several times that): a PROBE child then exits with status 5 (`--ranks
+    auto` moves on to the next mode), a measured run carries on and marks its line scaling_valid = false.  Returns
+    (record, ok) identical on every rank."""
     from .capi import lib, check
     from .dist import ROW, COL
     rec, ok = {"bytes": nbytes, "reps": reps, "min_busbw_GBps_required": MIN_BUSBW_GBPS}, True
@@ -105,7 +106,9 @@ def transport_proof(ctx, grid, comm, nbytes=256 << 20, reps=3):
     return rec, ok
 
 
-MIN_BUSBW_GBPS = float(os.environ.get("CHASE_HIP_MIN_BUSBW_GBPS", "40"))
+# the bar sits between what a host-staged ring over PCIe reaches (10-25 GB/s) and ONE xGMI link (~50 GB/s per direction: a
+# 2-rank row group of the 4 x 2 grid rides a single link, and the timed repetitions include the host-side event round trip)
+MIN_BUSBW_GBPS = float(os.environ.get("CHASE_HIP_MIN_BUSBW_GBPS", "30"))
 EXIT_TRANSPORT_TOO_SLOW = 5
 
 
@@ -141,9 +144,14 @@ def run_rank(args, comm, ctx, grid, mode):
     proof, proof_ok = transport_proof(ctx, grid, comm)
     if rank == 0:
         print("bench: transport proof " + json.dumps(proof), file=sys.stderr, flush=True)
-    if not proof_ok:
-        raise TransportTooSlow("a communicator moves less than %.0f GB/s (bus bandwidth of a 256 MB all-reduce): RCCL is not "
-                               "on xGMI peer-to-peer in mode '%s' - %s" % (MIN_BUSBW_GBPS, mode, json.dumps(proof)))
+    if not proof_ok and rank == 0:
+        # Round 5 (the advisor's finding): the bar was never calibrated on an xGMI box, so a slow communicator no longer ends
+        # the MEASURED run without a line - the probe children of `--ranks auto` have already walked bound -> unbound ->
+        # threads looking for a mode that passes; whatever mode runs now solves, and its line says transport_proof.ok = false
+        # and scaling_valid = false so that nobody reads a PCIe-staged number as an xGMI one
+        print("bench: WARNING: a communicator moves less than %.0f GB/s (bus bandwidth of a 256 MB all-reduce) in mode '%s': "
+              "the line below is marked scaling_valid = false - %s" % (MIN_BUSBW_GBPS, mode, json.dumps(proof)),
+              file=sys.stderr, flush=True)
     mb = nb = args.block_cyclic if args.block_cyclic >= 0 else B.DEFAULT_BLOCK_CYCLIC.get(workload, 0)
     rl, cl = cd.Layout(N, mb, nprow), cd.Layout(N, nb, npcol)
     pseudo = workload in B.PSEUDO_WORKLOADS
@@ -159,6 +167,18 @@ def run_rank(args, comm, ctx, grid, mode):
         s.set(device_rng=1)
     if os.environ.get("CHASE_HIP_PIPELINE") == "0":
         s.set(pipeline=0)            # development: every all-reduce waited for where it is issued (what the overlap is worth)
+    # first contact with the hardware: the knobs of the panel pipeline are measured on identical full-width filter steps and
+    # the best setting is locked BEFORE the first solve (chase_amd/autotune.py); untimed, a few seconds
+    tuned = None
+    if (world > 1 and not pseudo and not getattr(args, "no_autotune", False)
+            and (is_rccl or os.environ.get("CHASE_HIP_AUTOTUNE_HOST") == "1")):
+        from .autotune import first_contact
+        tuned = first_contact(s, ctx, grid, comm, nevex, budget=int(os.environ.get("CHASE_HIP_AUTOTUNE_TRIALS", "5")),
+                              log=(lambda m: print("bench: " + m, file=sys.stderr, flush=True)) if rank == 0 else None)
+        s.set(reset_counters=1)
+        for ph in range(4):
+            gemm_counters(ctx, ph, reset=True)
+        grid.comm_exposed_ms(reset=True)
 
     def snapshot():
         model, execd, calls = gemm_counters(ctx, 1)
@@ -234,6 +254,7 @@ def run_rank(args, comm, ctx, grid, mode):
             "ranks_seen_by_rccl": {"row_communicator": rccl_row, "col_communicator": rccl_col,
                                    "grid": rccl_row * rccl_col if is_rccl else None},
             "transport_proof": proof,
+            "scaling_valid": bool(proof_ok and ok),
             "comm_exposed_ms": exposed_ms, "comm_exposed_frac_of_wall": exposed_ms * 1e-3 / wall,
             "comm_waits": int(timer.diff("waits")),
             "roofline": B.roofline_object(model_flops, exec_flops, filt_s, calls, world,
@@ -241,6 +262,7 @@ def run_rank(args, comm, ctx, grid, mode):
         }
         out["roofline"]["whole_run"] = B.whole_run_object(tot, world)
         out["comm_probe"] = probe
+        out["autotune"] = tuned
     s.close()
     del dH
     return out

@@ -20,7 +20,9 @@
 // caller's host block of local rows (m x (nev+nex), ld = m; 2*(nev+nex) columns for pseudo-Hermitian problems) — read when
 // mode == 'A', written after the solve (End() copies the eigenvectors back, pchase_gpu.hpp:1010-1018); irsrc / icsrc must
 // be 0 (the reference's distribution functions assume it too, distMatrix.hpp:44-67 numroc with isrcproc = 0).
+#include <atomic>
 #include <complex>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -66,45 +68,53 @@ struct DistSlot {
     }
 };
 // One distributed solver per type like the reference's static members (chase_c_interface.cpp:905-1290): PROCESS-wide, so an
-// application may call p?chase_init_ on one thread and p?chase_ / get_eigenpairs / finalize on another (OpenMP regions, a
-// host language's worker threads, MPI_THREAD_MULTIPLE) exactly as with the reference.  Only when a SECOND thread
-// initialises a solver of the same type while the first one's is alive - several ranks of a grid living as threads of one
-// process, one per GPU - does that thread get a slot of its own, which its later calls find by thread id.
+// application may call p?chase_init_ on one thread, initialise AGAIN from another without a finalize in between (the
+// reference simply replaces its static solver) and call p?chase_ / get_eigenpairs / finalize from a third (OpenMP regions,
+// a host language's worker threads, MPI_THREAD_MULTIPLE).  The one exception is EXPLICIT (round 5; rounds 3-4 inferred it
+// from "a second thread initialises while a solver is alive", which captured exactly that legal re-initialisation): after
+// chase_hip_cshim_thread_ranks(1) every thread that initialises is a RANK of a grid living in this process - one thread per
+// GPU - and owns a slot of its own, which its later calls find by thread id.
+std::atomic<bool> g_thread_ranks{false};
 struct SlotTable {
     std::mutex mu;
     DistSlot global;
-    std::thread::id owner{};
-    bool claimed = false;
-    std::map<std::thread::id, std::unique_ptr<DistSlot>> extra;
+    std::map<std::thread::id, std::unique_ptr<DistSlot>> per_thread;
     DistSlot& for_init();
     // the calling thread ends (thread_local guard below): its own slot goes with it - thread ids are reused, and a stale
-    // entry would capture the init of whichever later thread happens to get the same id
+    // entry would capture the calls of whichever later thread happens to get the same id.  A rank thread that ends WITHOUT
+    // p?chase_finalize_ (a failing test, an exception path) leaves a solver that points into a context and a grid it only
+    // borrowed and that may be gone already: nothing borrowed is touched here - what the slot owns itself (the MPI front
+    // end's grid + context) is released, a borrowed-handle solver is abandoned with a note (the advisor's finding).
     void drop_thread()
     {
         std::unique_ptr<DistSlot> mine;
         {
             std::lock_guard<std::mutex> lk(mu);
-            auto it = extra.find(std::this_thread::get_id());
-            if (it == extra.end()) return;
+            auto it = per_thread.find(std::this_thread::get_id());
+            if (it == per_thread.end()) return;
             mine = std::move(it->second);
-            extra.erase(it);
+            per_thread.erase(it);
+        }
+        if (mine->s && !mine->own_grid) {
+            std::fprintf(stderr, "chase_hip: a rank thread ended without p?chase_finalize_: its solver is abandoned (the context "
+                                 "and grid it borrowed may be gone)\n");
+            mine->s = nullptr; mine->dH = nullptr; mine->ctx = nullptr; mine->grid = nullptr;
         }
         mine->clear();
     }
     DistSlot& current()
     {
         std::lock_guard<std::mutex> lk(mu);
-        auto it = extra.find(std::this_thread::get_id());
-        return it != extra.end() ? *it->second : global;
+        auto it = per_thread.find(std::this_thread::get_id());
+        return it != per_thread.end() ? *it->second : global;
     }
     void finalize()
     {
         DistSlot* mine = nullptr;
         {
             std::lock_guard<std::mutex> lk(mu);
-            auto it = extra.find(std::this_thread::get_id());
-            if (it != extra.end()) mine = it->second.get();        // stays this thread's (now empty) slot: what it sees from now on
-            else claimed = false;
+            auto it = per_thread.find(std::this_thread::get_id());
+            if (it != per_thread.end()) mine = it->second.get();   // stays this thread's (now empty) slot: what it sees from now on
         }
         (mine ? *mine : global).clear();
     }
@@ -116,11 +126,11 @@ DistSlot& SlotTable::for_init()
 {
     std::lock_guard<std::mutex> lk(mu);
     const auto me = std::this_thread::get_id();
-    auto it = extra.find(me);
-    if (it != extra.end()) return *it->second;
-    if (!claimed || owner == me) { claimed = true; owner = me; return global; }
+    auto it = per_thread.find(me);
+    if (it != per_thread.end()) return *it->second;
+    if (!g_thread_ranks.load()) return global;      // the reference's behaviour: one solver per type, replaced by a new init
     (void)&g_thread_slot_guard;                     // constructs this thread's guard: its destructor runs when the thread ends
-    auto& up = extra[me];
+    auto& up = per_thread[me];
     up.reset(new DistSlot());
     return *up;
 }
@@ -234,6 +244,10 @@ int chase_hip_cshim_use_ctx(chase_hip_ctx* ctx, int own)
     return 0;
 }
 chase_hip_solver* chase_hip_cshim_dist_solver(int cplx) { return cplx ? g_pz.s : g_pd.s; }
+/* on != 0: from now on every thread that calls a p?chase_init*_hip_ entry point is one RANK of a grid living in this process
+ * (one thread per GPU) and gets a solver slot of its own, found again by thread id; 0 (default): the reference's process-wide
+ * solver per type, which a new init from any thread replaces.  Returns the previous setting. */
+int chase_hip_cshim_thread_ranks(int on) { return g_thread_ranks.exchange(on != 0) ? 1 : 0; }
 
 /* ---- block layout (interface/chase_c_interface.h:126-149) ----------------------------------------------------------- */
 void pdchase_init_hip_(int* N, int* nev, int* nex, int* m, int* n, double* H, int* ldh, double* V, double* ritzv,

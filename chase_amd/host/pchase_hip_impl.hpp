@@ -165,8 +165,107 @@ public:
         is_sym_ = (bad == 0);
         return is_sym_;
     }
-    // the reference needs ScaLAPACK (p?tran) for this on a grid and throws without it (mpi/symOrHerm.hpp:128-320)
-    void symOrHermMatrix(char) override { throw std::logic_error("pChaseHip: symOrHermMatrix not available on shards"); }
+    // Completes the Hermitian matrix from ONE stored triangle on the distributed block (linalg/internal/mpi/symOrHerm.hpp:127-320,
+    // nccl/symOrHerm.hpp, called from Impl/pchase_gpu/pchase_gpu.hpp:643-647): the triangle `uplo` is kept, the other one
+    // zeroed and the diagonal halved, then H += H^H.  The reference needs ScaLAPACK's p?tranc for the transpose and throws
+    // without it; here the transpose is two pairwise exchanges with the communicators the grid already has (no world
+    // communicator, any transport), block and block-cyclic layouts alike.  With S(r, c) = the global indices whose ROW owner is
+    // grid row r and whose COLUMN owner is grid column c, rank (r, c) needs H[S(pr, c), S(r, pc)] from every rank (pr, pc):
+    //   hop 1, inside the column groups: (pr, pc) sends its local columns S(r, pc) to (r, pc), all its rows;
+    //   hop 2, inside the row groups:    (r, pc) passes on to (r, c) the rows of those pieces that belong to column set c,
+    //                                    and (r, c) adds their conjugate transposes into its rows S(r, pc).
+    // One-off set-up work (as large as the local block): staging is allocated for the call and released.
+    void symOrHermMatrix(char uplo) override
+    {
+        CHASE_PHASE(ctx_, "symOrHermMatrix");
+        if (uplo == 'u') uplo = 'U';
+        if (uplo == 'l') uplo = 'L';
+        if (uplo != 'U' && uplo != 'L') throw std::invalid_argument("symOrHermMatrix: uplo must be 'U' or 'L'");
+        flush_swaps(); sync_comm(); hv_valid_ = false;
+        hip_ok(chase_hip_tri_mask_bc(ctx_, CP, uplo, (int)m_, (int)n_, dH_, (long)ldh_, Rr_.nb, nprow_, myrow_, Cc_.nb, npcol_, mycol_),
+               "tri_mask_bc");
+        // ---- index sets (host arithmetic over the local indices) ------------------------------------------------------------
+        std::vector<std::vector<int>> cols1(nprow_);        // hop 1: my local COLUMNS by the grid row that owns them as rows
+        for (long jl = 0; jl < (long)n_; ++jl) cols1[Rr_.owner(Cc_.global(jl, mycol_))].push_back((int)jl);
+        std::vector<std::vector<int>> rows_of(npcol_);      // my local ROWS by the grid column that owns them as columns
+        for (long il = 0; il < (long)m_; ++il) rows_of[Cc_.owner(Rr_.global(il, myrow_))].push_back((int)il);
+        const std::size_t s_mine = cols1[myrow_].size();    // |S(myrow, mycol)|
+        if (rows_of[mycol_].size() != s_mine) throw std::logic_error("symOrHermMatrix: inconsistent index sets");
+        // hop 2 send side: rows of piece pr (its local rows l, global Rr.global(l, pr)) that go to grid column c2
+        std::vector<std::vector<std::vector<int>>> rows2(npcol_, std::vector<std::vector<int>>(nprow_));
+        std::vector<int> rowmap;                            // hop 2 receive side: row a of a received piece -> my local column
+        for (int pr = 0; pr < nprow_; ++pr)
+            for (long l = 0; l < Rr_.count(pr); ++l) {
+                const long g = Rr_.global(l, pr);
+                const int c2 = Cc_.owner(g);
+                rows2[c2][pr].push_back((int)l);
+                if (c2 == mycol_) rowmap.push_back((int)Cc_.local(g));
+            }
+        if (rowmap.size() != n_) throw std::logic_error("symOrHermMatrix: inconsistent row map");
+        std::size_t max_cols1 = 0, max_from = 0, max_ncount = 0;
+        for (auto& v : cols1) max_cols1 = std::max(max_cols1, v.size());
+        for (auto& v : rows_of) max_from = std::max(max_from, v.size());
+        for (int c2 = 0; c2 < npcol_; ++c2) max_ncount = std::max(max_ncount, (std::size_t)Cc_.count(c2));
+        // ---- staging -------------------------------------------------------------------------------------------------------
+        const std::size_t z_elems = N_ * s_mine, pack1 = m_ * max_cols1, psend = max_ncount * s_mine, precv = n_ * max_from;
+        std::vector<void*> tmp;
+        auto talloc = [&](std::size_t bytes) {
+            void* q = nullptr;
+            int rc = chase_hip_malloc(ctx_, &q, std::max<std::size_t>(bytes, 16));
+            if (rc) throw HipStatusError(rc, "symOrHermMatrix staging");
+            tmp.push_back(q);
+            return q;
+        };
+        auto tints = [&](const std::vector<int>& v) {
+            int* d = (int*)talloc(std::max<std::size_t>(v.size(), 1) * sizeof(int));
+            if (!v.empty()) hip_ok(chase_hip_memcpy_h2d(ctx_, d, v.data(), v.size() * sizeof(int)), "h2d");
+            return d;
+        };
+        try {
+            T* Z = (T*)talloc(z_elems * sizeof(T));
+            T* buf1 = (T*)talloc(std::max(pack1, psend) * sizeof(T));
+            T* buf2 = (T*)talloc(precv * sizeof(T));
+            std::vector<std::size_t> zoff(nprow_ + 1, 0);
+            for (int pr = 0; pr < nprow_; ++pr) zoff[pr + 1] = zoff[pr] + (std::size_t)Rr_.count(pr) * s_mine;
+            // ---- hop 1: column group, partner of step s is (s - me) mod p (an involution: both sides name each other) ------------
+            for (int st = 0; st < nprow_; ++st) {
+                const int peer = ((st - myrow_) % nprow_ + nprow_) % nprow_;
+                const std::vector<int>& cl = cols1[peer];
+                int* d_idx = tints(cl);
+                hip_ok(chase_hip_cols_indexed(ctx_, CP, (int)m_, dH_, (long)ldh_, buf1, (long)m_, d_idx, (int)cl.size()), "cols_indexed");
+                coll(chase_hip_grid_sendrecv(grid_, CHASE_HIP_COL, buf1, m_ * cl.size() * E, peer, Z + zoff[peer],
+                                             (std::size_t)Rr_.count(peer) * s_mine * E, peer));
+            }
+            // ---- hop 2: row group ------------------------------------------------------------------------------------------------
+            int* d_rowmap = tints(rowmap);
+            for (int st = 0; st < npcol_; ++st) {
+                const int peer = ((st - mycol_) % npcol_ + npcol_) % npcol_;
+                const std::size_t prow = (std::size_t)Cc_.count(peer);       // rows of the piece I pack for `peer`
+                std::size_t roff = 0;
+                for (int pr = 0; pr < nprow_; ++pr) {
+                    const std::vector<int>& rl = rows2[peer][pr];
+                    if (rl.empty() || s_mine == 0) { roff += rl.size(); continue; }
+                    int* d_idx = tints(rl);
+                    hip_ok(chase_hip_rows_indexed(ctx_, CP, Z + zoff[pr], (long)Rr_.count(pr), buf1 + roff, (long)prow, d_idx,
+                                                  (int)rl.size(), (int)s_mine, 0), "rows_indexed");
+                    roff += rl.size();
+                }
+                if (roff != prow) throw std::logic_error("symOrHermMatrix: packed piece has the wrong row count");
+                const std::size_t from = rows_of[peer].size();               // |S(myrow, peer)|: columns of what I receive
+                coll(chase_hip_grid_sendrecv(grid_, CHASE_HIP_ROW, buf1, prow * s_mine * E, peer, buf2, n_ * from * E, peer));
+                int* d_colmap = tints(rows_of[peer]);
+                hip_ok(chase_hip_conj_transpose_add(ctx_, CP, (int)n_, (int)from, buf2, (long)n_, d_rowmap, d_colmap, dH_, (long)ldh_),
+                       "conj_transpose_add");
+            }
+            hip_ok(chase_hip_ctx_sync(ctx_), "sync");
+        } catch (...) {
+            chase_hip_ctx_sync(ctx_);
+            for (void* q : tmp) chase_hip_free(ctx_, q);
+            throw;
+        }
+        for (void* q : tmp) chase_hip_free(ctx_, q);
+        is_sym_ = true;
+    }
     void Sort(R*, R*, R*) override {}
     void ApplyKconjugate(std::size_t) override {}
     void HEMM_H2(std::size_t, T, T, T, std::size_t, std::size_t = 0) override
@@ -187,6 +286,19 @@ public:
     std::size_t local_rows() const override { return m_; }
     std::size_t local_cols_h() const { return n_; }
     void set_pipeline(bool f) { pipeline_ = f; }
+    // Run-time knobs of the panel pipeline (first-contact self-tuning of bench.py --gpus N: they cannot be tuned without the
+    // hardware the job runs on).  Collective: every rank must set the same value at the same point of its call sequence (the
+    // panel grid defines which columns one all-reduce carries).  Anything in flight is waited for first; the per-panel
+    // events of the old grid are all complete by then, so a slot index may mean another column range afterwards.
+    void set_panel_cols(std::size_t w)
+    {
+        if (w < 64 || w > 4096 || w % 64) throw std::invalid_argument("panel_cols: a multiple of 64 in [64, 4096]");
+        flush_swaps(); sync_comm();
+        panel_ = w;
+    }
+    std::size_t panel_cols() const { return panel_; }
+    void set_panel_rounds(int r) { if (r < 0 || r > 16) throw std::invalid_argument("panel_rounds: 0..16"); panel_rounds_ = r; }
+    int panel_rounds() const { return panel_rounds_; }
 
     // ---- life cycle ----------------------------------------------------------------------------------------------------
     void Start() override { locked_ = 0; }
@@ -669,7 +781,7 @@ protected:
         const bool pipe = pipelined && pipeline_ && (active || other_active);
         // the panel products run beside the previous panel's all-reduce: finer work units, so that the CUs the collective
         // takes displace a fraction of a tile (chase_hip_ctx_set_gemm_min_rounds; CHASE_HIP_PANEL_ROUNDS, 0 = off)
-        static const int panel_rounds = [] { const char* e = std::getenv("CHASE_HIP_PANEL_ROUNDS"); return e ? std::atoi(e) : 4; }();
+        const int panel_rounds = panel_rounds_;
         // restored on every way out: hip_ok / coll throw, and a context left in forced K-split mode would give every later
         // product another decomposition (and rounding)
         struct RoundsGuard {
@@ -908,6 +1020,7 @@ protected:
     std::size_t m_ = 0, n_ = 0;
     std::size_t locked_ = 0, lanczosIter_ = 0, numLanczos_ = 0;
     std::size_t panel_ = 256;
+    int panel_rounds_ = [] { const char* e = std::getenv("CHASE_HIP_PANEL_ROUNDS"); return e ? std::atoi(e) : 4; }();
     bool next_bAc_ = true, device_rng_ = false, pipeline_ = true, pseudo_ = false, is_sym_ = true;
     bool hv_valid_ = false, resd_reuse_ = std::getenv("CHASE_HIP_RESD_REUSE") ? std::atoi(std::getenv("CHASE_HIP_RESD_REUSE")) != 0 : true;
     std::size_t hv_locked_ = 0, hv_block_ = 0, hemm_reused_vecs_ = 0;

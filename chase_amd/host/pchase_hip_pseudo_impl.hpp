@@ -45,6 +45,7 @@ public:
     bool checkSymmetryEasy() override { return false; }
     bool checkPseudoHermicityEasy() override { return true; }
     void Shift(T, bool = false) override {}                   // the H^2 filter carries the shift in gamma
+    void symOrHermMatrix(char) override {}          // a pseudo-Hermitian matrix has no triangle to complete (chase_cpu.hpp pseudo: no-op)
     void HEMM(std::size_t, T, T, std::size_t, std::size_t = 0) override
     {
         throw std::logic_error("pChaseHipPseudo: the pseudo-Hermitian filter uses HEMM_H2");

@@ -184,7 +184,7 @@ int chase_hip_solver_set(chase_hip_solver* s, const char* key, double v)
     if (!s || !key) return chase_hip::set_error(CHASE_HIP_EINVAL, "solver_set: NULL argument");
     const std::string name(key);
     int rc = 0;
-    DISPATCH(s, {
+    const int grc = guarded("solver_set", [&] { DISPATCH(s, {
         auto& c = k.GetConfig();
         if (name == "tol") c.SetTol(v);
         else if (name == "deg") c.SetDeg((size_t)v);
@@ -200,10 +200,12 @@ int chase_hip_solver_set(chase_hip_solver* s, const char* key, double v)
         else if (name == "clusteraware") c.SetClusterAwareDegrees(v != 0);
         else if (name == "upperbscale") c.SetUpperbScaleRate((float)v);
         else if (name == "device_rng") s->ex->set_device_rng(v != 0);
+        else if (name == "panel_cols" && (s->pd || s->pz)) { if (s->pz) s->pz->set_panel_cols((size_t)v); else s->pd->set_panel_cols((size_t)v); }
+        else if (name == "panel_rounds" && (s->pd || s->pz)) { if (s->pz) s->pz->set_panel_rounds((int)v); else s->pd->set_panel_rounds((int)v); }
         else if (name == "reset_counters") s->ex->reset_counters();
         else rc = chase_hip::set_error(CHASE_HIP_EINVAL, "solver_set: unknown key");
-    });
-    return rc;
+    }); });
+    return grc ? grc : rc;
 }
 
 int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* out)
@@ -227,6 +229,8 @@ int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* out)
         else if (name == "clusteraware") *out = c.UseClusterAwareDegrees();
         else if (name == "upperbscale") *out = c.GetUpperbScaleRate();
         else if (name == "locked") *out = (double)s->ex->locked();
+        else if (name == "panel_cols" && (s->pd || s->pz)) *out = (double)(s->pz ? s->pz->panel_cols() : s->pd->panel_cols());
+        else if (name == "panel_rounds" && (s->pd || s->pz)) *out = (double)(s->pz ? s->pz->panel_rounds() : s->pd->panel_rounds());
         else if (name == "qr_variant") *out = (double)s->ex->last_qr_variant();
         else if (name == "filter_ms") *out = s->ex->filter_ms();
         else if (name == "hemm_calls") *out = (double)s->ex->hemm_calls();
@@ -425,6 +429,10 @@ int chase_hip_op_lanczos_dos(chase_hip_solver* s, size_t idx, size_t m, void* ri
         if (s->cplx) s->z->LanczosDos(idx, m, (std::complex<double>*)ritzVc);
         else s->d->LanczosDos(idx, m, (double*)ritzVc);
     });
+}
+int chase_hip_op_sym_or_herm(chase_hip_solver* s, char uplo)
+{
+    return guarded("symOrHermMatrix", [&] { DISPATCH(s, k.symOrHermMatrix(uplo)); });
 }
 int chase_hip_op_check_symmetry(chase_hip_solver* s, int* is_sym)
 {

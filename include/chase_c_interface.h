@@ -73,6 +73,10 @@ struct chase_hip_ctx;
 struct chase_hip_solver;
 int chase_hip_cshim_use_ctx(struct chase_hip_ctx* ctx, int own); /* context of the NEXT _hip_ init; own: finalize destroys grid + ctx */
 struct chase_hip_solver* chase_hip_cshim_dist_solver(int cplx); /* the live distributed solver (chase_hip_solver.h), or NULL */
+/* 1: every thread that calls a p?chase_init*_hip_ entry point from now on is one RANK of a grid living in this process (one
+ * thread per GPU) with a solver of its own; 0 (default): ONE solver per type in the process, replaced by the next init from
+ * any thread - the reference's static members (interface/chase_c_interface.cpp:905-1290).  Returns the previous setting. */
+int chase_hip_cshim_thread_ranks(int on);
 struct chase_hip_solver* chase_hip_cshim_seq_solver(int kind); /* live sequential solver: 0 real, 1 complex, 2 complex pseudo-Hermitian */
 void pdchase_init_hip_(int* N, int* nev, int* nex, int* m, int* n, double* H, int* ldh, double* V, double* ritzv,
                        struct chase_hip_grid* grid, int* init);

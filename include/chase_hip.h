@@ -121,6 +121,16 @@ int chase_hip_fill_normal_bc(chase_hip_ctx* ctx, int cplx, int m, int n, void* X
  * linalg/distMatrix/distMultiVector.hpp:2444-2720) */
 int chase_hip_rows_indexed(chase_hip_ctx* ctx, int cplx, const void* in, long ld_in, void* out, long ld_out,
                            const int* idx_dev, int np, int ncols, int scatter);
+/* column gather by a device index list: out[:, c] = in[:, idx[c]], c < ncols */
+int chase_hip_cols_indexed(chase_hip_ctx* ctx, int cplx, int m, const void* in, long ld_in, void* out, long ld_out,
+                           const int* idx_dev, int ncols);
+/* the two local steps of the distributed symOrHermMatrix (linalg/internal/mpi/symOrHerm.hpp:127-320): the triangle mask of a
+ * block-cyclic shard by global position (kept triangle untouched, the other one zeroed, diagonal halved), and
+ * H[colmap[b], rowmap[a]] += conj(P[a, b]) - the conjugate transpose of a received piece added into the shard */
+int chase_hip_tri_mask_bc(chase_hip_ctx* ctx, int cplx, char uplo, int mloc, int nloc, void* H, long ldh, long mb, int pr, int pi,
+                          long nb, int pc, int pj);
+int chase_hip_conj_transpose_add(chase_hip_ctx* ctx, int cplx, int nr, int nc, const void* P, long ldp, const int* rowmap_dev,
+                                 const int* colmap_dev, void* H, long ldh);
 /* Clement-type test matrix of the reference's solve tests (tests/chase_serial_solve.cpp:52-90), any 2D shard:
  * H = scale * (Clement + perturb * G), G dense Hermitian N(0,1) on the entries the reference perturbs */
 int chase_hip_gen_clement(chase_hip_ctx* ctx, int cplx, void* H, long ldh, int mloc, int nloc, long N, int mb, int pr,

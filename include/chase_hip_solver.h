@@ -111,6 +111,10 @@ int chase_hip_op_lanczos(chase_hip_solver* s, size_t M, size_t numvec, double* u
                          double* ritzV);
 int chase_hip_op_lanczos_dos(chase_hip_solver* s, size_t idx, size_t m, void* ritzVc);
 int chase_hip_op_check_symmetry(chase_hip_solver* s, int* is_sym);
+/* symOrHermMatrix(uplo) (algorithm/interface.hpp:259): complete the Hermitian matrix from its stored triangle 'U' / 'L'.
+ * Sequential Impl: on the caller's host copy (linalg/internal/cpu/symOrHerm.hpp); distributed Impl: in place on the device
+ * shards, collective over the grid (linalg/internal/mpi/symOrHerm.hpp:127-320 without ScaLAPACK) */
+int chase_hip_op_sym_or_herm(chase_hip_solver* s, char uplo);
 
 #ifdef __cplusplus
 }

@@ -280,6 +280,59 @@ def scenario_solve_counts(ctx, grid, comm, N, nev, nex, cplx, mb, deg):
     s.close()
 
 
+def scenario_knob_switching(ctx, grid, comm, N, nev, nex, cplx, mb, deg):
+    """The run-time knobs of the panel pipeline (panel width, K-piece granularity, one / two communication streams:
+    chase_amd/autotune.py) switched BETWEEN THE ITERATIONS of a solve, on every rank at the same iteration: iteration and
+    filtered-vector counts, eigenvalues and the bitwise equality of the eigenvector replicas must survive - the knobs change how
+    a product is cut and overlapped, never what it computes beyond rounding."""
+    from chase_amd import autotune as A
+    H = O.clement(N, cplx)
+    rl, cl = cd.Layout(N, mb, grid.nprow), cd.Layout(N, mb, grid.npcol)
+    dH = ctx.array(cd.local_block_of(H, rl, cl, grid.myrow, grid.mycol))
+    s = cd.DistSolver(ctx, grid, dH, N, nev, nex, cplx, mb, mb)
+    s.set(deg=deg)
+    base = A.current_setting(s, grid)
+    assert base["comm_streams"] == 2 and base["panel_rounds"] == 4 and base["panel_cols"] >= 256
+    st0 = s.solve()
+    lam0 = s.ritzv[:nev].copy()
+    cycle = [{"panel_cols": 64, "panel_rounds": 0, "comm_streams": 1}, {"panel_cols": 512, "panel_rounds": 4, "comm_streams": 2},
+             {"panel_cols": 128, "panel_rounds": 2, "comm_streams": 1}, {"panel_cols": 256, "panel_rounds": 0, "comm_streams": 2}]
+    seen = []
+
+    def hook(it, filtered, locked, unconverged):
+        A.apply_setting(s, grid, cycle[it % len(cycle)])
+        seen.append(A.current_setting(s, grid))
+        return False
+
+    A.apply_setting(s, grid, cycle[-1])
+    s.set_iteration_hook(hook)
+    st1 = s.solve()
+    s.set_iteration_hook(None)
+    assert len(seen) == st1["iterations"] and seen[0] == cycle[0]
+    assert (st1["iterations"], st1["filtered_vecs"]) == (st0["iterations"], st0["filtered_vecs"])
+    lam1 = s.ritzv[:nev].copy()
+    assert np.max(np.abs(lam1 - lam0)) < 1e-9 and np.max(s.resid()[:nev]) < 1e-8
+    assert np.max(s.recompute_residuals(nev)) < 1e-8
+    objs = comm.all_gather_object((grid.myrow, grid.mycol, s.local_V()[:, :nev], lam1))
+    first = {}
+    for (i, j, blk, lam) in objs:
+        assert np.array_equal(lam, objs[0][3])                       # identical Ritz values on every rank
+        if i in first:
+            assert np.array_equal(first[i], blk), "column-type replicas differ after switching the knobs mid-solve"
+        else:
+            first[i] = blk
+    # out-of-range values are refused, the setting stays
+    from chase_amd.capi import ChaseHipError
+    for bad in ({"panel_cols": 100}, {"panel_cols": 8192}, {"panel_rounds": 99}):
+        try:
+            s.set(**bad)
+            raise AssertionError(f"accepted {bad}")
+        except ChaseHipError:
+            pass
+    assert A.current_setting(s, grid) == seen[-1]
+    s.close()
+
+
 def scenario_symcheck(ctx, grid, comm, cplx, mb):
     """Distributed randomized Hermiticity test (mpi/symOrHerm.hpp:46-96): true on a Hermitian matrix, false on every
     rank once a single off-diagonal entry is changed anywhere."""
@@ -295,6 +348,55 @@ def scenario_symcheck(ctx, grid, comm, cplx, mb):
         s = cd.DistSolver(ctx, grid, dH, N, 8, 4, cplx, mb, mb)
         got = s.checkSymmetryEasy()
         assert got == expect, (got, expect)
+        s.close()
+
+
+def scenario_sym_or_herm(ctx, grid, comm, cplx, mb):
+    """Distributed symOrHermMatrix (linalg/internal/mpi/symOrHerm.hpp:127-320; the reference needs ScaLAPACK for it): first the
+    reference's own test (tests/linalg/internal/mpi/symOrHerm.cpp:37-137: a 5 x 5 triangular matrix is not symmetric, after
+    symOrHermMatrix it is), then a random matrix of awkward size whose completed form is compared ENTRY BY ENTRY with
+    keep(H) + keep(H)^H computed on the host, for both triangles, on this grid's layout (mb = 0: block; else block-cyclic)."""
+    dt = np.complex128 if cplx else np.float64
+    # the reference's 5 x 5 known answer (column-major list of its test; stored triangle kept -> diagonal matrix in its 'U' case)
+    U = np.zeros((5, 5), dtype=dt, order="F")
+    vals = iter(range(1, 16))
+    for j in range(5):
+        for i in range(j, 5):
+            U[i, j] = next(vals)                       # U[0]=1, U[1]=2 ... exactly tests/linalg/internal/mpi/symOrHerm.cpp:47-71
+    for uplo, M in (("U", U), ("L", U.T.copy(order="F"))):
+        rl, cl = cd.Layout(5, min(mb, 2) if mb else 0, grid.nprow), cd.Layout(5, min(mb, 2) if mb else 0, grid.npcol)
+        nbb = min(mb, 2) if mb else 0
+        if rl.count(grid.myrow) == 0 or cl.count(grid.mycol) == 0:
+            blk = np.zeros((max(rl.count(grid.myrow), 1), max(cl.count(grid.mycol), 1)), dtype=dt, order="F")
+        else:
+            blk = cd.local_block_of(M, rl, cl, grid.myrow, grid.mycol)
+        dH = ctx.array(blk)
+        s = cd.DistSolver(ctx, grid, dH, 5, 2, 1, cplx, nbb, nbb, ldh=blk.shape[0])
+        assert not s.checkSymmetryEasy()
+        s.symOrHermMatrix(uplo)
+        assert s.checkSymmetryEasy()
+        s.close()
+    # entry-by-entry on a random matrix
+    N = 203
+    rng = np.random.default_rng(5)
+    H = rng.standard_normal((N, N)) + (1j * rng.standard_normal((N, N)) if cplx else 0)
+    H = np.asfortranarray(H.astype(dt))
+    rl, cl = cd.Layout(N, mb, grid.nprow), cd.Layout(N, mb, grid.npcol)
+    for uplo in ("U", "L"):
+        keep = np.triu(H, 1) if uplo == "U" else np.tril(H, -1)
+        want = keep + keep.conj().T + np.diag(np.real(np.diag(H))).astype(dt)   # diagonal: d/2 + conj(d/2) = Re d
+        dH = ctx.array(cd.local_block_of(H, rl, cl, grid.myrow, grid.mycol))
+        s = cd.DistSolver(ctx, grid, dH, N, 8, 4, cplx, mb, mb)
+        assert not s.checkSymmetryEasy()
+        s.symOrHermMatrix(uplo.lower() if uplo == "L" else uplo)
+        got = dH.download()
+        assert np.array_equal(got, cd.local_block_of(want, rl, cl, grid.myrow, grid.mycol)), np.max(np.abs(got - cd.local_block_of(want, rl, cl, grid.myrow, grid.mycol)))
+        assert s.checkSymmetryEasy()
+        try:
+            s.symOrHermMatrix("X")
+            raise AssertionError("accepted uplo = 'X'")
+        except Exception as e:
+            assert "uplo" in str(e)
         s.close()
 
 
@@ -545,6 +647,11 @@ def scenario_cshim(ctx, grid, comm, cplx, mb):
     I = lambda v: C.byref(C.c_int(v))
     init = C.c_int(0)
     p = "pz" if cplx else "pd"
+    # ranks that are THREADS of this process own one solver each: said explicitly (chase_hip_cshim_thread_ranks); ranks that
+    # are processes use the reference's one-solver-per-process slot
+    rank_threads = hasattr(comm, "w") and world > 1
+    if rank_threads:
+        lib.chase_hip_cshim_thread_ranks(1)
     lib.chase_hip_cshim_use_ctx(C.c_void_p(ctx.h.value), 0)
     if mb:
         getattr(lib, p + "chase_init_blockcyclic_hip_")(I(N), I(nev), I(nex), I(mb), I(mb), C.c_void_p(Hloc.ctypes.data), I(m),
@@ -611,6 +718,8 @@ def scenario_cshim(ctx, grid, comm, cplx, mb):
     comm.barrier()
     if rank == 0:
         os.remove(path)
+        if rank_threads:
+            lib.chase_hip_cshim_thread_ranks(0)
 
 
 def scenario_p2p(ctx, grid, comm):
@@ -657,6 +766,10 @@ def run_named(scen, ctx, grid, comm, argv):
         scenario_qr_fixtures(ctx, grid, comm, z(argv[0]), int(argv[1]) if len(argv) > 1 else 0)
     elif scen == "symcheck":
         scenario_symcheck(ctx, grid, comm, z(argv[0]), int(argv[1]))
+    elif scen == "sym_or_herm":
+        scenario_sym_or_herm(ctx, grid, comm, z(argv[0]), int(argv[1]))
+    elif scen == "knobs":
+        scenario_knob_switching(ctx, grid, comm, int(argv[0]), int(argv[1]), int(argv[2]), z(argv[3]), int(argv[4]), int(argv[5]))
     elif scen == "cshim":
         scenario_cshim(ctx, grid, comm, z(argv[0]), int(argv[1]))
     elif scen == "p2p":

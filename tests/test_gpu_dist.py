@@ -32,6 +32,17 @@ def test_operators_vs_oracle(nranks, typ, mb):
     run(nranks, S.scenario_ops, typ == "z", mb)
 
 
+@pytest.mark.parametrize("nranks,cplx,mb", [(4, True, 16), (8, False, 32)])
+def test_pipeline_knobs_switched_between_iterations(nranks, cplx, mb):
+    run(nranks, S.scenario_knob_switching, 640, 40, 24, cplx, mb, 20)
+
+
+@pytest.mark.parametrize("nranks,typ,mb", [(4, "d", 0), (4, "z", 0), (4, "z", 16), (8, "z", 0), (8, "d", 8), (6, "z", 0), (6, "d", 16),
+                                           (2, "z", 32), (1, "d", 0)])
+def test_distributed_sym_or_herm_matrix(nranks, typ, mb):
+    run(nranks, S.scenario_sym_or_herm, typ == "z", mb)
+
+
 def test_solve_block_2x2_n256_complex():
     run(4, S.scenario_solve, 256, 24, 16, True, 0, 16)
 
@@ -150,9 +161,8 @@ def test_pseudo_grid_solver_takes_the_reference_distributed_path_count_for_count
 
 def test_c_interface_slot_is_process_wide_like_the_reference(ctx):
     """The reference keeps one static distributed solver per type for the PROCESS (chase_c_interface.cpp:905-1290): an
-    application may call p?chase_init_ on one thread and p?chase_ / get_eigenpairs / finalize on another.  (Only when a second
-    thread initialises a solver of the same type while the first is alive - rank threads of one process - does it get its
-    own slot: every other test of this file.)"""
+    application may call p?chase_init_ on one thread and p?chase_ / get_eigenpairs / finalize on another.  (Threads get slots of
+    their own only after chase_hip_cshim_thread_ranks(1) - rank threads of one process: scenario_cshim.)"""
     import ctypes as C
     import threading
     import numpy as np
@@ -183,5 +193,51 @@ def test_c_interface_slot_is_process_wide_like_the_reference(ctx):
     assert np.max(O.residuals(H, ritzv[:nev], V[:, :nev])) < 1e-8
     flag = C.c_int(3)
     lib.pdchase_finalize_(C.byref(flag))
+    assert flag.value == 0 and not lib.chase_hip_cshim_dist_solver(0)
+    grid.close()
+
+
+def test_c_interface_reinit_from_another_thread_replaces_the_solver(ctx):
+    """init on thread A, init AGAIN on thread B without a finalize in between, solve on thread C: legal with the reference,
+    whose static solver is simply replaced (chase_c_interface.cpp:905-1290) - the second problem is the one that is solved, from
+    any thread (the advisor's finding of round 4: the second init used to land in a private slot of thread B)."""
+    import ctypes as C
+    import threading
+    import numpy as np
+    from chase_amd.capi import lib
+    from chase_amd import dist as cd
+    from oracle import chase_oracle as O
+    assert lib.chase_hip_cshim_thread_ranks(0) == 0
+    I = lambda v: C.byref(C.c_int(v))
+    grid = cd.Grid(ctx, 1, 1, 0, transport="host", pg=None)
+    probs = []
+    for N, nev, nex in ((160, 12, 10), (220, 18, 12)):
+        probs.append({"N": N, "nev": nev, "nex": nex, "H": np.asfortranarray(O.clement(N, False)),
+                      "V": np.zeros((N, nev + nex), order="F"), "ritzv": np.zeros(nev + nex), "init": C.c_int(0)})
+
+    def init(pr):
+        lib.chase_hip_cshim_use_ctx(C.c_void_p(ctx.h.value), 0)
+        lib.pdchase_init_hip_(I(pr["N"]), I(pr["nev"]), I(pr["nex"]), I(pr["N"]), I(pr["N"]), C.c_void_p(pr["H"].ctypes.data),
+                              I(pr["N"]), C.c_void_p(pr["V"].ctypes.data), C.c_void_p(pr["ritzv"].ctypes.data),
+                              C.c_void_p(grid.h.value), C.byref(pr["init"]))
+
+    for pr in probs:                                   # thread A, then thread B
+        t = threading.Thread(target=init, args=(pr,))
+        t.start(); t.join()
+        assert pr["init"].value == 1, lib.chase_hip_last_error()
+
+    def solve():
+        deg, tol = C.c_int(20), C.c_double(1e-10)
+        lib.pdchase_(C.byref(deg), C.byref(tol), C.c_char_p(b"R"), C.c_char_p(b"S"), C.c_char_p(b"C"))
+
+    t = threading.Thread(target=solve)                 # thread C
+    t.start(); t.join()
+    a, b = probs
+    assert not np.any(a["ritzv"]) and not np.any(a["V"])                   # the replaced solver's buffers were never touched
+    assert np.max(np.abs(b["ritzv"][:b["nev"]] - (-b["N"] + 2.0 * np.arange(b["nev"])))) < 1e-4
+    assert np.max(O.residuals(b["H"], b["ritzv"][:b["nev"]], b["V"][:, :b["nev"]])) < 1e-8
+    flag = C.c_int(3)
+    lib.pdchase_finalize_(C.byref(flag))
+    lib.chase_hip_cshim_dist_solver.restype = C.c_void_p
     assert flag.value == 0 and not lib.chase_hip_cshim_dist_solver(0)
     grid.close()

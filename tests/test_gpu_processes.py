@@ -96,6 +96,11 @@ def test_real_rccl_collectives_on_the_2x2_grid():
     distributed Householder QR"""
     run_ranks(4, "rccl", "ops", "d", 0, env_extra=FAKE_HOSTS)
     run_ranks(4, "rccl", "solve", 1001, 100, 60, "d", 64, 20, env_extra=FAKE_HOSTS)
+    # round 5: panel width / K-piece granularity / one-or-two communication streams switched between the iterations of a
+    # solve over REAL asynchronous collectives (what the first-contact self-tuning of bench.py --gpus N relies on)
+    run_ranks(4, "rccl", "knobs", 640, 40, 24, "z", 16, 20, env_extra=FAKE_HOSTS)
+    # round 5: symOrHermMatrix on the grid - two pairwise exchanges (ncclSend / ncclRecv) inside the column and row groups
+    run_ranks(4, "rccl", "sym_or_herm", "z", 16, env_extra=FAKE_HOSTS)
     run_ranks(4, "rccl", "pseudo_solve", 0, env_extra=FAKE_HOSTS)
     run_ranks(4, "rccl", "qr_fixtures", "z", 0, env_extra=FAKE_HOSTS)
 
