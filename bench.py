@@ -719,6 +719,13 @@ def main():
                     help="single-rank replay (chase_amd/replay.py): e.g. 4x2 or 4x2,2x2,2x1 - ONE rank of each grid is driven "
                          "through the taped call sequence of a real single-GPU solve of the workload on a loopback grid (no "
                          "communication): the compute side of the multi-GPU solve, measured on one GPU")
+    ap.add_argument("--loopback-busbw", default=None, metavar="GBPS[,GBPS...]",
+                    help="replay: MODEL the absent collectives - each all-reduce / broadcast holds its communication stream and "
+                         "32 workgroups for latency + wire bytes / this bus bandwidth (0 = nothing enqueued); one replay per value")
+    ap.add_argument("--loopback-latency-us", type=float, default=20.0)
+    ap.add_argument("--replay-panel", type=int, default=0, help="replay: panel width of the pipelined HEMM (columns)")
+    ap.add_argument("--replay-comm-streams", type=int, default=0, help="replay: 1 or 2 communication streams")
+    ap.add_argument("--replay-no-pipeline", action="store_true", help="replay: every collective waited for where it is issued")
     ap.add_argument("--tape", default=None, help="scalar tape file (.npz): loaded if it exists, else recorded and saved there")
     ap.add_argument("--replay-rank-index", type=int, default=0, help="which rank of the grid is replayed (default 0 = (0,0))")
     ap.add_argument("--oplog-out", default=None, help="write the replayed rank's operator log there (%%g = grid)")

@@ -26,23 +26,30 @@ using namespace chase_hip;
         }                                                                                                              \
     } while (0)
 
-// one read + write pass over a collective's payload (loopback_touch): what a ring all-reduce costs this device's HBM
-__global__ void loopback_touch_kernel(double* x, size_t n)
+// Stand-in for a collective on the loopback transport: a few workgroups (RCCL runs its rings on a handful of CUs) make one read
+// + write pass over the payload (touch: the HBM traffic a ring all-reduce causes on this device) and then stay resident until
+// `ticks` of the constant 100 MHz clock have passed since they started - the time the modelled collective would hold its
+// communication stream and its CUs (chase_hip_grid_set_loopback_model).
+__global__ void loopback_model_kernel(double* x, size_t n, int touch, unsigned long long ticks)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const double v = __builtin_nontemporal_load(x + i);
-        __builtin_nontemporal_store(v, x + i);
+    const unsigned long long t0 = (unsigned long long)wall_clock64();
+    if (touch) {
+        const size_t stride = (size_t)gridDim.x * blockDim.x;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            const double v = __builtin_nontemporal_load(x + i);
+            __builtin_nontemporal_store(v, x + i);
+        }
     }
+    while ((unsigned long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
-static int loopback_touch_launch(hipStream_t st, double* x, size_t n)
+static int loopback_model_launch(hipStream_t st, double* x, size_t n, bool touch, double seconds, double clock_hz)
 {
-    if (!n) return 0;
-    // few workgroups, like a collective's kernels (RCCL runs its rings on a handful of CUs)
+    if (!n || (!touch && seconds <= 0)) return 0;
     const int blocks = (int)std::min<size_t>(32, (n + 255) / 256);
-    hipLaunchKernelGGL(loopback_touch_kernel, dim3(blocks), dim3(256), 0, st, x, n);
+    const unsigned long long ticks = seconds > 0 ? (unsigned long long)(seconds * clock_hz) : 0ull;
+    hipLaunchKernelGGL(loopback_model_kernel, dim3(blocks), dim3(256), 0, st, x, n, touch ? 1 : 0, ticks);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "loopback_touch_kernel");
+    if (e != hipSuccess) return hip_fail(e, "loopback_model_kernel");
     return 0;
 }
 
@@ -181,8 +188,27 @@ int chase_hip_grid_create_loopback(chase_hip_grid** out, chase_hip_ctx* ctx, int
     int rc = grid_common(g, ctx, nprow, npcol, rank);
     if (rc) { chase_hip_grid_destroy(g); return rc; }
     g->loopback = true;
+    {   // rate of wall_clock64 on this device (100 MHz on gfx950; asked, not assumed)
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) == hipSuccess && khz > 0) g->wall_clock_hz = khz * 1e3;
+    }
     if (const char* e = getenv("CHASE_HIP_LOOPBACK_TOUCH")) g->loopback_touch = atoi(e) != 0;
+    if (const char* e = getenv("CHASE_HIP_LOOPBACK_BUSBW_GBPS")) g->lb_busbw_GBps = atof(e);
+    if (const char* e = getenv("CHASE_HIP_LOOPBACK_LATENCY_US")) g->lb_latency_us = atof(e);
     *out = g;
+    return 0;
+}
+/* Duration model of the collectives a loopback grid does not perform: every all-reduce / broadcast then holds its communication
+ * stream - and a collective's handful of workgroups - for latency_us + wire bytes / busbw_GBps (bus bandwidth as RCCL's tests
+ * define it: an all-reduce of S bytes among p ranks puts 2 (p - 1) / p S on the wire per rank, a broadcast S); touch != 0 adds
+ * one read + write pass over the payload.  busbw_GBps = 0: nothing is enqueued (the compute side alone).  What it is for: the
+ * replayed rank's overlap machinery (per-panel events, two streams, exposed-wait brackets) then runs against collectives of
+ * a chosen, STATED speed - a model, never a measurement of xGMI. */
+int chase_hip_grid_set_loopback_model(chase_hip_grid* g, double busbw_GBps, double latency_us, int touch)
+{
+    if (!g || !g->loopback) return set_error(CHASE_HIP_EINVAL, "set_loopback_model: not a loopback grid");
+    if (busbw_GBps < 0 || latency_us < 0) return set_error(CHASE_HIP_EINVAL, "set_loopback_model: negative argument");
+    g->lb_busbw_GBps = busbw_GBps; g->lb_latency_us = latency_us; g->loopback_touch = touch != 0;
     return 0;
 }
 
@@ -256,8 +282,11 @@ static int collective(chase_hip_grid* g, int mode, int group, void* dev, size_t 
         if (g->use_rccl) {
             if (mode == 0) NCCLCHK(ncclAllReduce(dev, dev, count, ncclDouble, ncclSum, g->comm[group], cs));
             else NCCLCHK(ncclBroadcast(dev, dev, count, ncclDouble, root, g->comm[group], cs));
-        } else if (g->loopback_touch) {
-            int rc = loopback_touch_launch(cs, (double*)dev, count);
+        } else if (g->loopback_touch || g->lb_busbw_GBps > 0) {
+            const int p = g->group_size(group);
+            const double wire = (mode == 0 ? 2.0 * (p - 1) / p : 1.0) * (double)count * sizeof(double);
+            const double secs = g->lb_busbw_GBps > 0 ? g->lb_latency_us * 1e-6 + wire / (g->lb_busbw_GBps * 1e9) : 0.0;
+            int rc = loopback_model_launch(cs, (double*)dev, count, g->loopback_touch, secs, g->wall_clock_hz);
             if (rc) return rc;
         }
         g->pending[g->stream_index(group)] = true;
