@@ -723,7 +723,9 @@ def main():
                     help="replay: MODEL the absent collectives - each all-reduce / broadcast holds its communication stream and "
                          "32 workgroups for latency + wire bytes / this bus bandwidth (0 = nothing enqueued); one replay per value")
     ap.add_argument("--loopback-latency-us", type=float, default=20.0)
+    ap.add_argument("--loopback-wgs", default="32", help="replay: workgroups a modelled collective holds (comma list)")
     ap.add_argument("--replay-panel", type=int, default=0, help="replay: panel width of the pipelined HEMM (columns)")
+    ap.add_argument("--replay-panel-rounds", type=int, default=-1, help="replay: K-piece granularity of the panel products (0 = off)")
     ap.add_argument("--replay-comm-streams", type=int, default=0, help="replay: 1 or 2 communication streams")
     ap.add_argument("--replay-no-pipeline", action="store_true", help="replay: every collective waited for where it is issued")
     ap.add_argument("--tape", default=None, help="scalar tape file (.npz): loaded if it exists, else recorded and saved there")

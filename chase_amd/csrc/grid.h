@@ -20,6 +20,7 @@ struct chase_hip_grid {
     // stream - and a collective's share of CUs - for latency + wire bytes / bus bandwidth (RCCL's definition of bus bandwidth:
     // an all-reduce of S bytes among p ranks moves 2 (p - 1) / p S per rank); 0 = nothing is enqueued
     double lb_busbw_GBps = 0.0, lb_latency_us = 0.0, wall_clock_hz = 1e8;
+    int lb_wgs = 32;                                  // workgroups of the stand-in kernel (RCCL: one per channel)
     bool force = false;                               // CHASE_HIP_RCCL_FORCE: run size-1 groups through RCCL too (testing)
     ncclComm_t comm[2] = {nullptr, nullptr};          // [ROW], [COL]
     // one communication stream per group: on a 4 x 2 grid the row and column communicators use disjoint xGMI links, so

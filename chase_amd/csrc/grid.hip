@@ -30,8 +30,12 @@ using namespace chase_hip;
 // + write pass over the payload (touch: the HBM traffic a ring all-reduce causes on this device) and then stay resident until
 // `ticks` of the constant 100 MHz clock have passed since they started - the time the modelled collective would hold its
 // communication stream and its CUs (chase_hip_grid_set_loopback_model).
-__global__ void loopback_model_kernel(double* x, size_t n, int touch, unsigned long long ticks)
+// FOOTPRINT: an RCCL kernel is 512 threads per workgroup with up to 128 VGPRs per thread (its launch bounds) - eight such
+// waves do not fit on a CU beside the TWO workgroups of the MFMA GEMM (2 waves x ~250 VGPRs per SIMD), so a resident collective
+// workgroup costs the GEMM a workgroup slot.  The stand-in claims the same: 512 threads, v127 touched.
+__global__ __launch_bounds__(512) void loopback_model_kernel(double* x, size_t n, int touch, unsigned long long ticks)
 {
+    asm volatile("v_mov_b32 v127, 0" ::: "v127");
     const unsigned long long t0 = (unsigned long long)wall_clock64();
     if (touch) {
         const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -42,12 +46,12 @@ __global__ void loopback_model_kernel(double* x, size_t n, int touch, unsigned l
     }
     while ((unsigned long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
-static int loopback_model_launch(hipStream_t st, double* x, size_t n, bool touch, double seconds, double clock_hz)
+static int loopback_model_launch(hipStream_t st, double* x, size_t n, bool touch, double seconds, double clock_hz, int wgs)
 {
     if (!n || (!touch && seconds <= 0)) return 0;
-    const int blocks = (int)std::min<size_t>(32, (n + 255) / 256);
+    const int blocks = (int)std::min<size_t>((size_t)std::max(wgs, 1), (n + 511) / 512);
     const unsigned long long ticks = seconds > 0 ? (unsigned long long)(seconds * clock_hz) : 0ull;
-    hipLaunchKernelGGL(loopback_model_kernel, dim3(blocks), dim3(256), 0, st, x, n, touch ? 1 : 0, ticks);
+    hipLaunchKernelGGL(loopback_model_kernel, dim3(blocks), dim3(512), 0, st, x, n, touch ? 1 : 0, ticks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "loopback_model_kernel");
     return 0;
@@ -195,20 +199,24 @@ int chase_hip_grid_create_loopback(chase_hip_grid** out, chase_hip_ctx* ctx, int
     if (const char* e = getenv("CHASE_HIP_LOOPBACK_TOUCH")) g->loopback_touch = atoi(e) != 0;
     if (const char* e = getenv("CHASE_HIP_LOOPBACK_BUSBW_GBPS")) g->lb_busbw_GBps = atof(e);
     if (const char* e = getenv("CHASE_HIP_LOOPBACK_LATENCY_US")) g->lb_latency_us = atof(e);
+    if (const char* e = getenv("CHASE_HIP_LOOPBACK_WGS")) g->lb_wgs = std::max(1, atoi(e));
     *out = g;
     return 0;
 }
 /* Duration model of the collectives a loopback grid does not perform: every all-reduce / broadcast then holds its communication
- * stream - and a collective's handful of workgroups - for latency_us + wire bytes / busbw_GBps (bus bandwidth as RCCL's tests
+ * stream - and `workgroups` workgroups of an RCCL kernel's footprint (512 threads, 128 VGPRs; 0 keeps the current count,
+ * default 32) - for latency_us + wire bytes / busbw_GBps (bus bandwidth as RCCL's tests
  * define it: an all-reduce of S bytes among p ranks puts 2 (p - 1) / p S on the wire per rank, a broadcast S); touch != 0 adds
  * one read + write pass over the payload.  busbw_GBps = 0: nothing is enqueued (the compute side alone).  What it is for: the
  * replayed rank's overlap machinery (per-panel events, two streams, exposed-wait brackets) then runs against collectives of
  * a chosen, STATED speed - a model, never a measurement of xGMI. */
-int chase_hip_grid_set_loopback_model(chase_hip_grid* g, double busbw_GBps, double latency_us, int touch)
+int chase_hip_grid_set_loopback_model(chase_hip_grid* g, double busbw_GBps, double latency_us, int touch, int workgroups)
 {
     if (!g || !g->loopback) return set_error(CHASE_HIP_EINVAL, "set_loopback_model: not a loopback grid");
-    if (busbw_GBps < 0 || latency_us < 0) return set_error(CHASE_HIP_EINVAL, "set_loopback_model: negative argument");
+    if (busbw_GBps < 0 || latency_us < 0 || workgroups < 0 || workgroups > 1024)
+        return set_error(CHASE_HIP_EINVAL, "set_loopback_model: bad argument");
     g->lb_busbw_GBps = busbw_GBps; g->lb_latency_us = latency_us; g->loopback_touch = touch != 0;
+    if (workgroups > 0) g->lb_wgs = workgroups;
     return 0;
 }
 
@@ -286,7 +294,7 @@ static int collective(chase_hip_grid* g, int mode, int group, void* dev, size_t 
             const int p = g->group_size(group);
             const double wire = (mode == 0 ? 2.0 * (p - 1) / p : 1.0) * (double)count * sizeof(double);
             const double secs = g->lb_busbw_GBps > 0 ? g->lb_latency_us * 1e-6 + wire / (g->lb_busbw_GBps * 1e9) : 0.0;
-            int rc = loopback_model_launch(cs, (double*)dev, count, g->loopback_touch, secs, g->wall_clock_hz);
+            int rc = loopback_model_launch(cs, (double*)dev, count, g->loopback_touch, secs, g->wall_clock_hz, g->lb_wgs);
             if (rc) return rc;
         }
         g->pending[g->stream_index(group)] = true;

@@ -14,7 +14,7 @@ AR_FN = C.CFUNCTYPE(c_int, c_void_p, c_int, P(c_double), c_size_t)
 BC_FN = C.CFUNCTYPE(c_int, c_void_p, c_int, P(c_double), c_size_t, c_int)
 _sig("chase_hip_grid_create_host", c_int, P(c_void_p), c_void_p, c_int, c_int, c_int, AR_FN, BC_FN, c_void_p)
 _sig("chase_hip_grid_create_loopback", c_int, P(c_void_p), c_void_p, c_int, c_int, c_int)
-_sig("chase_hip_grid_set_loopback_model", c_int, c_void_p, c_double, c_double, c_int)
+_sig("chase_hip_grid_set_loopback_model", c_int, c_void_p, c_double, c_double, c_int, c_int)
 _sig("chase_hip_grid_set_comm_streams", c_int, c_void_p, c_int)
 _sig("chase_hip_grid_comm_streams", c_int, c_void_p)
 _sig("chase_hip_grid_event_record_on", c_int, c_void_p, c_int, c_int)
@@ -208,9 +208,11 @@ class Grid:
         check(lib.chase_hip_grid_transport(self.h, C.byref(a), C.byref(r), C.byref(c)), "grid_transport")
         return a.value == 1, r.value, c.value
 
-    def set_loopback_model(self, busbw_GBps, latency_us=0.0, touch=False):
-        """loopback grids: collectives hold their stream for latency + wire bytes / bus bandwidth (a stated model)"""
-        check(lib.chase_hip_grid_set_loopback_model(self.h, float(busbw_GBps), float(latency_us), int(touch)), "set_loopback_model")
+    def set_loopback_model(self, busbw_GBps, latency_us=0.0, touch=False, workgroups=0):
+        """loopback grids: collectives hold their stream and `workgroups` RCCL-sized workgroups for latency + wire bytes / bus
+        bandwidth (a stated model)"""
+        check(lib.chase_hip_grid_set_loopback_model(self.h, float(busbw_GBps), float(latency_us), int(touch), int(workgroups)),
+              "set_loopback_model")
 
     def set_comm_streams(self, n):
         """1: both groups' collectives on one communication stream, 2: one stream per group (default)."""

@@ -73,7 +73,8 @@ def replay_rank(ctx, tape, meta, nprow, npcol, rank=0, block_cyclic=None, oplog=
         grid.set_comm_streams(settings["comm_streams"])
     model = (settings or {}).get("loopback_model")
     if model:
-        grid.set_loopback_model(model.get("busbw_GBps", 0.0), model.get("latency_us", 0.0), model.get("touch", False))
+        grid.set_loopback_model(model.get("busbw_GBps", 0.0), model.get("latency_us", 0.0), model.get("touch", False),
+                                model.get("workgroups", 0))
     rl, cl = cd.Layout(N, nb, nprow), cd.Layout(N, nb, npcol)
     dH = cd.gen_clement_local(ctx, N, cplx, rl, cl, grid.myrow, grid.mycol, scale=B.MATRIX_SCALE / N, perturb=B.MATRIX_PERTURB)
     ctx.sync()
@@ -83,6 +84,8 @@ def replay_rank(ctx, tape, meta, nprow, npcol, rank=0, block_cyclic=None, oplog=
         s.set(pipeline=settings["pipeline"])
     if settings and settings.get("panel_cols"):
         s.set(panel_cols=settings["panel_cols"])
+    if settings and settings.get("panel_rounds") is not None:
+        s.set(panel_rounds=settings["panel_rounds"])
     tape_load(s, tape)
     tape_mode(s, 2)
     per_iter = []
@@ -132,8 +135,9 @@ def replay_rank(ctx, tape, meta, nprow, npcol, rank=0, block_cyclic=None, oplog=
            "gemm_books": books, "per_iteration": per_iter,
            "comm_streams": grid.comm_streams(),
            "collectives": ("none enqueued (compute side alone)" if not model else
-                           "MODELLED: each holds its stream and 32 workgroups for %.0f us + wire bytes / %.0f GB/s bus bandwidth%s"
-                           % (model.get("latency_us", 0.0), model.get("busbw_GBps", 0.0),
+                           "MODELLED: each holds its stream and %d workgroups (512 threads, 128 VGPRs) for %.0f us + wire bytes / "
+                           "%.0f GB/s bus bandwidth%s"
+                           % (model.get("workgroups", 0) or 32, model.get("latency_us", 0.0), model.get("busbw_GBps", 0.0),
                               ", plus one read+write pass over the payload" if model.get("touch") else "")),
            "loopback_model": model, "settings": {k: v for k, v in (settings or {}).items() if k != "loopback_model"}}
     if lines is not None:
@@ -176,8 +180,10 @@ def run(args):
            "single_gpu": meta, "replays": []}
     variants = [None]
     if args.loopback_busbw:
-        variants = [None if float(b) <= 0 else {"busbw_GBps": float(b), "latency_us": args.loopback_latency_us, "touch": True}
-                    for b in args.loopback_busbw.split(",")]
+        variants = [None if float(b) <= 0 else {"busbw_GBps": float(b), "latency_us": args.loopback_latency_us, "touch": True,
+                                                "workgroups": int(w)}
+                    for b in args.loopback_busbw.split(",") for w in str(args.loopback_wgs).split(",")]
+        variants = [v for i, v in enumerate(variants) if v is not None or None not in variants[:i]]
     base_settings = {}
     if args.replay_panel:
         base_settings["panel_cols"] = args.replay_panel
@@ -185,6 +191,8 @@ def run(args):
         base_settings["comm_streams"] = args.replay_comm_streams
     if args.replay_no_pipeline:
         base_settings["pipeline"] = 0
+    if args.replay_panel_rounds >= 0:
+        base_settings["panel_rounds"] = args.replay_panel_rounds
     for spec, model in [(g, m) for g in args.replay_rank.split(",") for m in variants]:
         r, c = (int(x) for x in spec.lower().split("x"))
         rec, lines = replay_rank(ctx, tape, meta, r, c, rank=args.replay_rank_index, oplog=bool(args.oplog_out), log=log,
@@ -193,7 +201,7 @@ def run(args):
         rec["compute_side_speedup_bound"] = meta["solve_seconds"] / rec["T_rank_seconds"]
         rec["compute_side_efficiency_bound"] = meta["solve_seconds"] / (ranks * rec["T_rank_seconds"])
         out["replays"].append(rec)
-        log(f"replay {spec} [{rec['collectives'][:40]}]: exposed {rec['exposed_ms_of_those_waits_with_nothing_on_the_wire']:.0f} ms; T_rank = {rec['T_rank_seconds']:.2f} s (single GPU {meta['solve_seconds']:.1f} s): compute-side "
+        log(f"replay {spec} [{rec['collectives'][:46]}, {(model or {}).get('busbw_GBps', 0):.0f} GB/s]: exposed {rec['exposed_ms_of_those_waits_with_nothing_on_the_wire']:.0f} ms; T_rank = {rec['T_rank_seconds']:.2f} s (single GPU {meta['solve_seconds']:.1f} s): compute-side "
             f"speed-up bound {rec['compute_side_speedup_bound']:.2f}x of {ranks}, phases {rec['phases']}")
         if args.oplog_out and lines is not None:
             with open(args.oplog_out.replace("%g", spec), "w") as f:

@@ -45,11 +45,12 @@ int chase_hip_grid_create_host(chase_hip_grid** out, chase_hip_ctx* ctx, int npr
  * solve (bench.py --replay-rank 4x2): results are wrong by construction, the compute side's time is right. */
 int chase_hip_grid_create_loopback(chase_hip_grid** out, chase_hip_ctx* ctx, int nprow, int npcol, int rank);
 /* Duration model of the collectives a loopback grid does not perform: each all-reduce / broadcast holds its communication
- * stream and a collective's handful of workgroups for latency_us + wire bytes / busbw_GBps (RCCL's bus bandwidth: an
+ * stream and `workgroups` workgroups with an RCCL kernel's footprint (512 threads, 128 VGPRs: they cannot share a CU with two
+ * workgroups of the MFMA GEMM; 0 = keep, default 32) for latency_us + wire bytes / busbw_GBps (RCCL's bus bandwidth: an
  * all-reduce of S bytes among p ranks puts 2 (p - 1) / p S on the wire per rank, a broadcast S); touch: plus one read + write
  * pass over the payload.  0 GB/s = nothing enqueued.  A stated MODEL for exercising the overlap machinery of the replayed
- * rank, never a measurement of xGMI (env: CHASE_HIP_LOOPBACK_BUSBW_GBPS / _LATENCY_US / _TOUCH). */
-int chase_hip_grid_set_loopback_model(chase_hip_grid* g, double busbw_GBps, double latency_us, int touch);
+ * rank, never a measurement of xGMI (env: CHASE_HIP_LOOPBACK_BUSBW_GBPS / _LATENCY_US / _TOUCH / _WGS). */
+int chase_hip_grid_set_loopback_model(chase_hip_grid* g, double busbw_GBps, double latency_us, int touch, int workgroups);
 int chase_hip_grid_destroy(chase_hip_grid* g);
 /* communication streams: 2 (default) = one per group - on a 4 x 2 grid the row and column communicators use disjoint xGMI
  * links, so their collectives do not queue behind each other; 1 = both groups on one stream (CHASE_HIP_COMM_STREAMS=1).
