@@ -191,6 +191,12 @@ class Context:
             check(lib.chase_hip_gemm_d(self.h, op, m, n, k, float(alpha), A, lda, B, ldb, float(beta), Cm, ldc),
                   "gemm_d")
 
+    def hash64(self, ptr, m, n, ld, cplx):
+        """64-bit content hash of a device matrix (chase_hip_hash64)"""
+        h = C.c_ulonglong()
+        check(lib.chase_hip_hash64(self.h, int(cplx), m, n, ptr, ld, C.byref(h)), "hash64")
+        return h.value
+
     def gen_clement(self, N, cplx, scale=1.0, perturb=0.0, seed=42):
         """Whole N x N Clement-type test matrix generated in HBM (see chase_hip_gen_clement)."""
         dH = self.empty((N, N), np.complex128 if cplx else np.float64)
@@ -310,6 +316,7 @@ _sig("chase_hip_solver_tape_load", c_int, c_void_p, c_void_p, c_size_t)
 _sig("chase_hip_resid_norms_dev", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p,
      c_void_p, c_int)
 _sig("chase_hip_solver_peek_v", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
+_sig("chase_hip_solver_hash_v", c_int, c_void_p, c_void_p, c_size_t, P(C.c_ulonglong))
 _sig("chase_hip_op_start", c_int, c_void_p)
 _sig("chase_hip_op_end", c_int, c_void_p)
 _sig("chase_hip_op_initvecs", c_int, c_void_p, c_int)
@@ -325,6 +332,7 @@ _sig("chase_hip_op_lanczos", c_int, c_void_p, c_size_t, c_size_t, P(c_double), c
 _sig("chase_hip_op_lanczos_dos", c_int, c_void_p, c_size_t, c_size_t, c_void_p)
 _sig("chase_hip_op_check_symmetry", c_int, c_void_p, P(c_int))
 _sig("chase_hip_op_sym_or_herm", c_int, c_void_p, c_char)
+_sig("chase_hip_hash64", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, P(C.c_ulonglong))
 _sig("chase_hip_cols_indexed", c_int, c_void_p, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_int)
 _sig("chase_hip_tri_mask_bc", c_int, c_void_p, c_int, c_char, c_int, c_int, c_void_p, c_long, c_long, c_int, c_int, c_long, c_int,
      c_int)

@@ -140,6 +140,26 @@ int chase_hip_rows_indexed(chase_hip_ctx* c, int cplx, const void* in, long ld_i
 /* local shard (mloc x nloc) of the N x N Clement-type test matrix.  Rows: global = roff + ((l / mb) * pr + pi) * mb +
  * l % mb; columns likewise with (nb, pc, pj, coff).  Whole matrix on one GPU: mb = nb = N, pr = pc = 1, rest 0.
  * H = scale * (Clement + perturb * Hermitian N(0,1)); perturb = 0 gives the unperturbed tridiagonal matrix. */
+/* 64-bit content hash of a device matrix (m x n, ld; position-mixed words summed modulo 2^64: order-independent, so
+ * reproducible) - lets two holders of what should be the same block compare it without moving it */
+int chase_hip_hash64(chase_hip_ctx* c, int cplx, int m, int n, const void* A, long lda, unsigned long long* out_host)
+{
+    if (!c || !out_host) return set_error(CHASE_HIP_EINVAL, "hash64: NULL argument");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (m < 0 || n < 0 || lda < m) return set_error(CHASE_HIP_EINVAL, "hash64: bad shape");
+    *out_host = 0;
+    if (m == 0 || n == 0) return 0;
+    if (!A) return set_error(CHASE_HIP_EINVAL, "hash64: NULL matrix");
+    const int e = ept_of(cplx);
+    RCCHK(c->ensure_buf(chase_hip_ctx::BUF_SCAL, 4096));
+    unsigned long long* d = (unsigned long long*)c->bufs[chase_hip_ctx::BUF_SCAL];
+    HIPCHK(hipMemsetAsync(d, 0, sizeof(unsigned long long), c->stream));
+    KCHK(hash64(c->stream, (const double*)A, lda * e, (long)m * e, n, d), "hash64");
+    HIPCHK(hipMemcpyAsync(out_host, d, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 /* out[:, c] = in[:, idx[c]], c < ncols (idx on the device): column gather, the counterpart of chase_hip_rows_indexed */
 int chase_hip_cols_indexed(chase_hip_ctx* c, int cplx, int m, const void* in, long ld_in, void* out, long ld_out,
                            const int* idx_dev, int ncols)

@@ -11,6 +11,7 @@
 // All scalars (tau, beta) stay on the device: no host synchronisation inside the factorisation.
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "../../include/chase_hip.h"
 #include "../../include/chase_hip_grid.h"
 #include "ctx.h"
@@ -18,7 +19,20 @@
 
 namespace chase_hip {
 
-constexpr int HNB = 32;
+constexpr int HNB = 32;        // sub-block width of the aggregated back-transformation (hh_apply_q_left)
+constexpr int HMAX = 48;       // capacity of the panel kernels: largest panel width of the QR drivers (larft_kernel keeps T in 36 KB of static LDS)
+
+// Panel width of the Householder QR drivers: 32 like the reference's (Impl/pchase_cpu/pchase_cpu.hpp:590-596,
+// Impl/pchase_gpu/pchase_gpu.hpp:1065, linalg/internal/mpi/householder_qr.hpp:47-59), overridden by the reference's own
+// CHASE_HOUSEHOLDER_NB (its outer block width; CHASE_QR_OUTER_BLOCK_NB is read as a synonym like the reference's
+// mpi_qr_block_nb_env does), clamped to what the panel kernels hold.  Read at every call like the reference does.
+static int householder_nb()
+{
+    int nb = HNB;
+    for (const char* name : {"CHASE_QR_OUTER_BLOCK_NB", "CHASE_HOUSEHOLDER_NB"})
+        if (const char* e = getenv(name)) { const long v = strtol(e, nullptr, 10); if (v > 0) nb = (int)(v > HMAX ? HMAX : v); }
+    return nb < 2 ? 2 : nb;
+}
 
 __device__ __forceinline__ double wsum(double v)
 {
@@ -144,10 +158,10 @@ __global__ __launch_bounds__(64) void larft_kernel(const double* __restrict__ G,
                                                    double* __restrict__ T)
 {
     constexpr int E = CPLX ? 2 : 1;
-    __shared__ double t[HNB * HNB * 2];
-    __shared__ double g[HNB * 2];
+    __shared__ double t[HMAX * HMAX * 2];
+    __shared__ double g[HMAX * 2];
     const int r = threadIdx.x;
-    for (int e = r; e < HNB * HNB * E; e += 64) t[e] = 0.0;
+    for (int e = r; e < HMAX * HMAX * E; e += 64) t[e] = 0.0;
     __syncthreads();
     for (int i = 0; i < nb; ++i) {
         const double tr = tau[i * E], ti = CPLX ? tau[i * E + 1] : 0.0;
@@ -156,18 +170,18 @@ __global__ __launch_bounds__(64) void larft_kernel(const double* __restrict__ G,
         if (r < i) {                                   // row r of upper-triangular T[0:i,0:i] times g
             double sr = 0.0, si = 0.0;
             for (int l = r; l < i; ++l) {
-                const double ar = t[(l * HNB + r) * E], ai = CPLX ? t[(l * HNB + r) * E + 1] : 0.0;
+                const double ar = t[(l * HMAX + r) * E], ai = CPLX ? t[(l * HMAX + r) * E + 1] : 0.0;
                 const double br = g[l * E], bi = CPLX ? g[l * E + 1] : 0.0;
                 sr += ar * br - ai * bi;
                 si += ar * bi + ai * br;
             }
-            t[(i * HNB + r) * E] = -(tr * sr - ti * si);
-            if (CPLX) t[(i * HNB + r) * E + 1] = -(tr * si + ti * sr);
+            t[(i * HMAX + r) * E] = -(tr * sr - ti * si);
+            if (CPLX) t[(i * HMAX + r) * E + 1] = -(tr * si + ti * sr);
         }
-        if (r == i) { t[(i * HNB + i) * E] = tr; if (CPLX) t[(i * HNB + i) * E + 1] = ti; }
+        if (r == i) { t[(i * HMAX + i) * E] = tr; if (CPLX) t[(i * HMAX + i) * E + 1] = ti; }
         __syncthreads();
     }
-    for (int e = r; e < HNB * HNB * E; e += 64) T[e] = t[e];
+    for (int e = r; e < HMAX * HMAX * E; e += 64) T[e] = t[e];
 }
 
 // Q (m x n, ld = m) <- first n columns of the identity
@@ -436,10 +450,11 @@ extern "C" int chase_hip_houseqr(chase_hip_ctx* c, int cplx_, int m, int n, void
     const int E = cplx ? 2 : 1;
     double* A = (double*)V_;
     hipStream_t st = c->stream;
-    const int npan = (n + HNB - 1) / HNB;
+    const int PNB = householder_nb();
+    const int npan = (n + PNB - 1) / PNB;
     // one scratch block: Q (m x n) | Vb (m x nb) | W1, W2 (nb x n) | G (nb x nb) | T (npan x nb x nb) | tau (n)
-    const size_t szQ = (size_t)m * n * E, szV = (size_t)m * HNB * E, szW = (size_t)HNB * n * E;
-    const size_t szG = (size_t)HNB * HNB * E, szT = (size_t)npan * HNB * HNB * E, szTau = (size_t)n * E;
+    const size_t szQ = (size_t)m * n * E, szV = (size_t)m * PNB * E, szW = (size_t)PNB * n * E;
+    const size_t szG = (size_t)PNB * PNB * E, szT = (size_t)npan * HMAX * HMAX * E, szTau = (size_t)n * E;
     double* blk = nullptr;
     hipError_t he = hipMalloc((void**)&blk, (szQ + szV + 2 * szW + szG + szT + szTau) * sizeof(double));
     if (he != hipSuccess) return set_error(CHASE_HIP_ENOMEM, "houseqr: scratch allocation failed");
@@ -448,7 +463,7 @@ extern "C" int chase_hip_houseqr(chase_hip_ctx* c, int cplx_, int m, int n, void
     int rc = 0;
     auto body = [&]() -> int {
         for (int p = 0; p < npan; ++p) {
-            const int j0 = p * HNB, nb = (n - j0 < HNB) ? n - j0 : HNB, pend = j0 + nb;
+            const int j0 = p * PNB, nb = (n - j0 < PNB) ? n - j0 : PNB, pend = j0 + nb;
             for (int j = j0; j < pend; ++j) {
                 if (cplx) KL(hipLaunchKernelGGL(house_gen_kernel<true>, dim3(1), dim3(256), 0, st, A, ldv, m, j, tau));
                 else      KL(hipLaunchKernelGGL(house_gen_kernel<false>, dim3(1), dim3(256), 0, st, A, ldv, m, j, tau));
@@ -462,14 +477,14 @@ extern "C" int chase_hip_houseqr(chase_hip_ctx* c, int cplx_, int m, int n, void
             unsigned gx = (unsigned)((rows + 1023) / 1024); if (gx > 64) gx = 64; if (gx < 1) gx = 1;
             KL(hipLaunchKernelGGL(extract_v_kernel, dim3(gx, nb), dim3(256), 0, st, A, ldv, m, j0, nb, E, Vb));
             RC(g3(c, cplx, 'C', nb, nb, rows, 1.0, Vb, rows, Vb, rows, 0.0, G, nb));
-            double* Tp = T + (size_t)p * HNB * HNB * E;
+            double* Tp = T + (size_t)p * HMAX * HMAX * E;
             if (cplx) KL(hipLaunchKernelGGL(larft_kernel<true>, dim3(1), dim3(64), 0, st, G, nb, tau + (size_t)j0 * E, Tp));
             else      KL(hipLaunchKernelGGL(larft_kernel<false>, dim3(1), dim3(64), 0, st, G, nb, tau + (size_t)j0 * E, Tp));
             const int nt = n - pend;
             if (nt > 0) {                               // C -= V T^H (V^H C)
                 double* Cm = A + ((long)pend * ldv + j0) * E;
                 RC(g3(c, cplx, 'C', nb, nt, rows, 1.0, Vb, rows, Cm, ldv, 0.0, W1, nb));
-                RC(g3(c, cplx, 'C', nb, nt, nb, 1.0, Tp, HNB, W1, nb, 0.0, W2, nb));
+                RC(g3(c, cplx, 'C', nb, nt, nb, 1.0, Tp, HMAX, W1, nb, 0.0, W2, nb));
                 RC(g3(c, cplx, 'N', rows, nt, nb, -1.0, Vb, rows, W2, nb, 1.0, Cm, ldv));
             }
         }
@@ -479,14 +494,14 @@ extern "C" int chase_hip_houseqr(chase_hip_ctx* c, int cplx_, int m, int n, void
             KL(hipLaunchKernelGGL(set_identity_kernel, dim3(gx, n), dim3(256), 0, st, Q, m, n, E));
         }
         for (int p = npan - 1; p >= 0; --p) {
-            const int j0 = p * HNB, nb = (n - j0 < HNB) ? n - j0 : HNB;
+            const int j0 = p * PNB, nb = (n - j0 < PNB) ? n - j0 : PNB;
             const int rows = m - j0, nq = n - j0;
             unsigned gx = (unsigned)((rows + 1023) / 1024); if (gx > 64) gx = 64; if (gx < 1) gx = 1;
             KL(hipLaunchKernelGGL(extract_v_kernel, dim3(gx, nb), dim3(256), 0, st, A, ldv, m, j0, nb, E, Vb));
-            double* Tp = T + (size_t)p * HNB * HNB * E;
+            double* Tp = T + (size_t)p * HMAX * HMAX * E;
             double* Qs = Q + ((long)j0 * m + j0) * E;                    // Q[j0:m, j0:n]
             RC(g3(c, cplx, 'C', nb, nq, rows, 1.0, Vb, rows, Qs, m, 0.0, W1, nb));
-            RC(g3(c, cplx, 'N', nb, nq, nb, 1.0, Tp, HNB, W1, nb, 0.0, W2, nb));
+            RC(g3(c, cplx, 'N', nb, nq, nb, 1.0, Tp, HMAX, W1, nb, 0.0, W2, nb));
             RC(g3(c, cplx, 'N', rows, nq, nb, -1.0, Vb, rows, W2, nb, 1.0, Qs, m));
         }
         int e = copy2d(st, Q, (long)m * E, A, ldv * E, (long)m * E, n);
@@ -520,12 +535,13 @@ extern "C" int chase_hip_houseqr_dist(chase_hip_ctx* c, chase_hip_grid* grid, in
     const int E = cplx ? 2 : 1;
     double* A = (double*)V_;
     hipStream_t st = c->stream;
-    const int npan = (n + HNB - 1) / HNB;
+    const int PNB = householder_nb();
+    const int npan = (n + PNB - 1) / PNB;
     const int ml = mloc > 0 ? mloc : 1;                              // keep leading dimensions valid on an empty rank
     // scratch: Q (mloc x n) | Vb (mloc x nb) | Wr (nb x (nb + n)) | W2 (nb x n) | T (npan x nb x nb) | tau (n) | buf
-    const size_t szQ = (size_t)ml * n * E, szV = (size_t)ml * HNB * E, szWr = (size_t)HNB * (HNB + n) * E;
-    const size_t szW2 = (size_t)HNB * n * E, szT = (size_t)npan * HNB * HNB * E, szTau = (size_t)n * E;
-    const size_t szBuf = 3 + 4 * (size_t)HNB + 8;
+    const size_t szQ = (size_t)ml * n * E, szV = (size_t)ml * PNB * E, szWr = (size_t)PNB * (PNB + n) * E;
+    const size_t szW2 = (size_t)PNB * n * E, szT = (size_t)npan * HMAX * HMAX * E, szTau = (size_t)n * E;
+    const size_t szBuf = 3 + 4 * (size_t)PNB + 8;
     double* blk = nullptr;
     if (hipMalloc((void**)&blk, (szQ + szV + szWr + szW2 + szT + szTau + szBuf) * sizeof(double)) != hipSuccess)
         return set_error(CHASE_HIP_ENOMEM, "houseqr_dist: scratch allocation failed");
@@ -533,7 +549,7 @@ extern "C" int chase_hip_houseqr_dist(chase_hip_ctx* c, chase_hip_grid* grid, in
     double* tau = T + szT; double* buf = tau + szTau;
     auto body = [&]() -> int {
         for (int p = 0; p < npan; ++p) {
-            const int j0 = p * HNB, nb = (n - j0 < HNB) ? n - j0 : HNB, pend = j0 + nb;
+            const int j0 = p * PNB, nb = (n - j0 < PNB) ? n - j0 : PNB, pend = j0 + nb;
             for (int j = j0; j < pend; ++j) {
                 const int nc = pend - j - 1;
                 if (cplx) KL(hipLaunchKernelGGL(dhh_partial_kernel<true>, dim3(1 + nc), dim3(256), 0, st, A, ldv, mloc, row_offset, j, nc, buf));
@@ -549,11 +565,11 @@ extern "C" int chase_hip_houseqr_dist(chase_hip_ctx* c, chase_hip_grid* grid, in
             if (nt > 0) RC(g3(c, cplx, 'C', nb, nt, mloc, 1.0, Vb, ml, A + (long)pend * ldv * E, ldv, 0.0, W1, nb));
             if (mloc == 0) HIPCHK_RET(hipMemsetAsync(Wr, 0, (size_t)nb * (nb + nt) * E * sizeof(double), st));
             RC(chase_hip_grid_allreduce(grid, group, Wr, (size_t)nb * (nb + nt) * E, 0));
-            double* Tp = T + (size_t)p * HNB * HNB * E;
+            double* Tp = T + (size_t)p * HMAX * HMAX * E;
             if (cplx) KL(hipLaunchKernelGGL(larft_kernel<true>, dim3(1), dim3(64), 0, st, Wr, nb, tau + (size_t)j0 * E, Tp));
             else      KL(hipLaunchKernelGGL(larft_kernel<false>, dim3(1), dim3(64), 0, st, Wr, nb, tau + (size_t)j0 * E, Tp));
             if (nt > 0) {                                            // C -= V T^H (V^H C)
-                RC(g3(c, cplx, 'C', nb, nt, nb, 1.0, Tp, HNB, W1, nb, 0.0, W2, nb));
+                RC(g3(c, cplx, 'C', nb, nt, nb, 1.0, Tp, HMAX, W1, nb, 0.0, W2, nb));
                 RC(g3(c, cplx, 'N', mloc, nt, nb, -1.0, Vb, ml, W2, nb, 1.0, A + (long)pend * ldv * E, ldv));
             }
             // the factored columns are dead (R is not needed): they become the store of the panel's reflectors
@@ -568,14 +584,14 @@ extern "C" int chase_hip_houseqr_dist(chase_hip_ctx* c, chase_hip_grid* grid, in
             KL(hipLaunchKernelGGL(set_identity_stacked_kernel, dim3(gx, n), dim3(256), 0, st, Q, mloc, row_offset, n, E));
         }
         for (int p = npan - 1; p >= 0; --p) {
-            const int j0 = p * HNB, nb = (n - j0 < HNB) ? n - j0 : HNB, nq = n - j0;
+            const int j0 = p * PNB, nb = (n - j0 < PNB) ? n - j0 : PNB, nq = n - j0;
             const double* Vp = A + (long)j0 * ldv * E;               // stored reflectors (zeros above the pivots included)
             double* Qs = Q + (long)j0 * ml * E;
             RC(g3(c, cplx, 'C', nb, nq, mloc, 1.0, Vp, ldv, Qs, ml, 0.0, Wr, nb));
             if (mloc == 0) HIPCHK_RET(hipMemsetAsync(Wr, 0, (size_t)nb * nq * E * sizeof(double), st));
             RC(chase_hip_grid_allreduce(grid, group, Wr, (size_t)nb * nq * E, 0));
-            double* Tp = T + (size_t)p * HNB * HNB * E;
-            RC(g3(c, cplx, 'N', nb, nq, nb, 1.0, Tp, HNB, Wr, nb, 0.0, W2, nb));
+            double* Tp = T + (size_t)p * HMAX * HMAX * E;
+            RC(g3(c, cplx, 'N', nb, nq, nb, 1.0, Tp, HMAX, Wr, nb, 0.0, W2, nb));
             RC(g3(c, cplx, 'N', mloc, nq, nb, -1.0, Vp, ldv, W2, nb, 1.0, Qs, ml));
         }
         if (mloc > 0) {

@@ -35,6 +35,7 @@ int copy2d(hipStream_t st, const double* src, long ld_src_d, double* dst, long l
 int swap_cols(hipStream_t st, double* a, double* b, long md);
 int rows_indexed(hipStream_t st, bool cplx, const double* in, long ld_in, double* out, long ld_out, const int* idx_dev,
                  int np, int ncols, int scatter);
+int hash64(hipStream_t st, const double* x, long ld_d, long md, int ncols, unsigned long long* out_dev);
 int tri_mask_bc(hipStream_t st, bool cplx, double* H, long ldh, int mloc, int nloc, long mb, int pr, int pi, long nb, int pc,
                 int pj, int keep_upper);
 int conj_transpose_add(hipStream_t st, bool cplx, const double* P, long ldp, int nr, int nc, const int* rowmap_dev,

@@ -403,6 +403,24 @@ __global__ __launch_bounds__(256) void conj_transpose_add_kernel(const double* _
     }
 }
 
+// 64-bit content hash of a strided block of 8-byte words (chase_hip_hash64): every word is mixed with its POSITION (column,
+// row) through a 64-bit finaliser and the mixed words are summed modulo 2^64 - integer addition is associative, so the result
+// does not depend on the order the atomics land in; two blocks that differ in one bit hash differently with probability
+// 1 - 2^-64.  What the multi-rank tests compare instead of downloading the replicas of an eigenvector block.
+__global__ __launch_bounds__(256) void hash64_kernel(const unsigned long long* __restrict__ x, long ld_w, long m_w, int ncols,
+                                                     unsigned long long* __restrict__ out)
+{
+    unsigned long long acc = 0;
+    for (int c = blockIdx.y; c < ncols; c += gridDim.y)
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < m_w; i += (long)gridDim.x * 256) {
+            unsigned long long v = x[(long)c * ld_w + i] ^ (0x9E3779B97F4A7C15ull * (unsigned long long)((long)c * m_w + i + 1));
+            v ^= v >> 33; v *= 0xff51afd7ed558ccdull; v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ull; v ^= v >> 33;
+            acc += v;
+        }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
 // A[i,j] = conj(A[j,i]) for i < j (rebuild the strictly-upper triangle from the lower one) and Im A[j,j] = 0
 __global__ void mirror_lower_kernel(double* __restrict__ A, long lda, int n, int ept)
 {
@@ -470,6 +488,12 @@ int copy_cols_indexed_range(hipStream_t st, const double* src, long ld_src_d, do
     if (cnt <= 0 || md <= 0) return 0;
     hipLaunchKernelGGL(copy_cols_indexed_kernel, grid2(md, cnt), dim3(256), 0, st, src, ld_src_d, dst + (long)dst0 * ld_dst_d,
                        ld_dst_d, md, src_idx_dev, (const int*)nullptr, cnt);
+    return (int)hipGetLastError();
+}
+int hash64(hipStream_t st, const double* x, long ld_d, long md, int ncols, unsigned long long* out_dev)
+{
+    if (md <= 0 || ncols <= 0) return 0;
+    hipLaunchKernelGGL(hash64_kernel, grid2(md, ncols), dim3(256), 0, st, (const unsigned long long*)x, ld_d, md, ncols, out_dev);
     return (int)hipGetLastError();
 }
 int tri_mask_bc(hipStream_t st, bool cplx, double* H, long ldh, int mloc, int nloc, long mb, int pr, int pi, long nb, int pc,

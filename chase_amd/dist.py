@@ -314,6 +314,12 @@ class DistSolver:
         check(lib.chase_hip_psolver_download_v(self.h, out.ctypes.data, self.m_loc), "download_v")
         return out
 
+    def hash_V(self, ncols):
+        """64-bit content hash of the first ncols columns of this rank's vector block, computed on the device"""
+        h = C.c_ulonglong()
+        check(lib.chase_hip_solver_hash_v(self.h, self.ctx.h, ncols, C.byref(h)), "hash_v")
+        return h.value
+
     def upload_local_V(self, V):
         V = np.asfortranarray(V, dtype=self.dt)
         check(lib.chase_hip_psolver_upload_v(self.h, V.ctypes.data, V.shape[0]), "upload_v")

@@ -445,6 +445,18 @@ int chase_hip_solver_recompute_residuals(chase_hip_solver* s, size_t ncols, cons
     return guarded("recompute_residuals", [&] { s->ex->recompute_residuals(ncols, lambda, resid); });
 }
 
+/* 64-bit content hash of the first ncols columns of the (local) vector block as it sits in HBM */
+int chase_hip_solver_hash_v(chase_hip_solver* s, chase_hip_ctx* ctx, size_t ncols, unsigned long long* hash)
+{
+    if (!s || !ctx || !hash) return chase_hip::set_error(CHASE_HIP_EINVAL, "hash_v: NULL argument");
+    return guarded("hash_v", [&] {
+        DISPATCH(s, {
+            if (ncols > k.GetRitzvBlockSize()) throw std::invalid_argument("more columns than the Impl holds");
+            hip_ok(chase_hip_hash64(ctx, s->cplx, (int)s->ex->local_rows(), (int)ncols, s->ex->device_V1(), (long)s->ex->local_rows(), hash), "hash64");
+        });
+    });
+}
+
 int chase_hip_solver_peek_v(chase_hip_solver* s, chase_hip_ctx* ctx, void* host, size_t ldh)
 {
     return guarded("peek_v", [&] {

@@ -121,6 +121,9 @@ int chase_hip_fill_normal_bc(chase_hip_ctx* ctx, int cplx, int m, int n, void* X
  * linalg/distMatrix/distMultiVector.hpp:2444-2720) */
 int chase_hip_rows_indexed(chase_hip_ctx* ctx, int cplx, const void* in, long ld_in, void* out, long ld_out,
                            const int* idx_dev, int np, int ncols, int scatter);
+/* 64-bit content hash of a device matrix (position-mixed 8-byte words summed modulo 2^64: independent of the order of
+ * evaluation, hence reproducible): two holders of what should be the same block compare 8 bytes instead of the block */
+int chase_hip_hash64(chase_hip_ctx* ctx, int cplx, int m, int n, const void* A, long lda, unsigned long long* out_host);
 /* column gather by a device index list: out[:, c] = in[:, idx[c]], c < ncols */
 int chase_hip_cols_indexed(chase_hip_ctx* ctx, int cplx, int m, const void* in, long ld_in, void* out, long ld_out,
                            const int* idx_dev, int ncols);

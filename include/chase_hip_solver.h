@@ -88,6 +88,9 @@ const char* chase_hip_solver_trace(chase_hip_solver* s);   /* '\n'-separated vir
  * Collective over the grid for the distributed Impls. */
 int chase_hip_solver_recompute_residuals(chase_hip_solver* s, size_t ncols, const double* lambda, double* resid);
 int chase_hip_solver_peek_v(chase_hip_solver* s, chase_hip_ctx* ctx, void* host, size_t ldh);
+/* chase_hip_hash64 of the first ncols columns of the Impl's (local) vector block, where it sits: the replicas of a block over
+ * the grid columns are compared by 8 bytes per rank instead of by download */
+int chase_hip_solver_hash_v(chase_hip_solver* s, chase_hip_ctx* ctx, size_t ncols, unsigned long long* hash);
 
 /* the ChaseBase virtuals */
 int chase_hip_op_start(chase_hip_solver* s);

@@ -448,6 +448,17 @@ def scenario_qr_fixtures(ctx, grid, comm, cplx, mb=0):
     v, o = run("cond_ill.bin", 1e12);  assert v in (0, 3) and o <= 25 * EPS                 # shifted CholQR2 or HHQR
     v, o = run("cond_ill.bin", 10.0);  assert v == 0 and o <= 25 * EPS                      # CholQR1 fails -> Householder
     v, o = run("cond_1e4.bin", 1e4, cholqr=0); assert v == 0 and o <= 25 * EPS              # Householder requested
+    # the reference's panel-width knob (CHASE_HOUSEHOLDER_NB, pchase_cpu.hpp:590-596 / pchase_gpu.hpp:1065), read at every QR:
+    # same assertions with panels of 8 and of 40 columns (every rank sets the same value; ranks that are threads share it)
+    for nb in ("8", "40"):
+        comm.barrier()
+        os.environ["CHASE_HOUSEHOLDER_NB"] = nb
+        comm.barrier()
+        v, o = run("cond_1e4.bin", 1e4, cholqr=0); assert v == 0 and o <= 25 * EPS
+        v, o = run("cond_ill.bin", 10.0);          assert v == 0 and o <= 25 * EPS
+        comm.barrier()
+    os.environ.pop("CHASE_HOUSEHOLDER_NB", None)
+    comm.barrier()
 
 
 def scenario_reference_run_counts(ctx, grid, comm):

@@ -6,7 +6,6 @@ eigenvalues against the known spectrum; tests/chase_distributed_solve_pseudo_bse
 is asserted here at the sizes BASELINE.json names instead of N = 1001.
 
 Used by tests/test_gpu_fullsize.py (driver-run) and scripts/dev_rehearsal_threads.py (prints the record)."""
-import hashlib
 import os
 import sys
 import time
@@ -57,9 +56,8 @@ def fullsize_rank(ctx, grid, comm, wl, nb, result, hash_replicas=True):
     # replicas: the column-type eigenvector block of a grid row is held by every member of that row group
     digest = None
     if hash_replicas:
-        V = s.local_V()
-        digest = hashlib.blake2b(np.ascontiguousarray(V[:, :nev].T).view(np.uint8), digest_size=16).hexdigest()
-        del V
+        # on the device, 8 bytes back per rank (round 4 downloaded 8 x 0.67 GB and hashed them on the host)
+        digest = s.hash_V(nev)
     resid_re = s.recompute_residuals(nev, lam)                  # fresh four-product H V (collective)
     everyone = comm.all_gather_object((grid.myrow, grid.mycol, lam, resid, digest, resid_re))
     if comm.rank == 0:

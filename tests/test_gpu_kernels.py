@@ -208,6 +208,25 @@ def test_houseqr_orthogonality_and_span(ctx, cplx, shape):
     assert np.linalg.norm(np.tril(R, -1)) <= 1e-11 * np.linalg.norm(R)   # R is upper triangular
 
 
+@pytest.mark.parametrize("nb", ["8", "17", "48", "200"])
+def test_houseqr_panel_width_knob_of_the_reference(ctx, nb, monkeypatch):
+    """CHASE_HOUSEHOLDER_NB (Impl/pchase_cpu/pchase_cpu.hpp:590-596, pchase_gpu.hpp:1065: the outer block width of the
+    reference's Householder QR; tests/linalg/internal/nccl/householder_qr.cpp:218-260 runs its test with the env knobs set):
+    read at every call, any width up to the panel kernels' capacity (larger values are clamped), same assertions"""
+    from chase_amd.capi import lib
+    monkeypatch.setenv("CHASE_HOUSEHOLDER_NB", nb)
+    for cplx, (m, n) in ((False, (500, 130)), (True, (301, 97))):
+        rng = np.random.default_rng(7)
+        V = rnd(rng, (m, n), cplx)
+        dV = ctx.array(V)
+        assert lib.chase_hip_houseqr(ctx.h, int(cplx), m, n, dV.ptr, m) == 0, lib.chase_hip_last_error()
+        Q = dV.download()
+        assert O.orthogonality(Q) <= 25 * EPS
+        R = Q.conj().T @ V
+        assert np.linalg.norm(V - Q @ R) <= 1e-12 * np.linalg.norm(V)
+        assert np.linalg.norm(np.tril(R, -1)) <= 1e-11 * np.linalg.norm(R)
+
+
 @pytest.mark.parametrize("cplx", [False, True])
 def test_houseqr_on_ill_conditioned_fixture(ctx, cplx):
     from chase_amd.capi import lib
@@ -673,3 +692,37 @@ def test_herkx_upper_block_trapezoid_matches_numpy(ctx, cplx, n, k):
     assert np.max(np.abs(G - gref) / (np.abs(Q).T @ np.abs(Q))) < 8 * GEMM_TOL
     for d in (dW, dQ, dA):
         d.free()
+
+
+def test_hash64_tells_blocks_apart_and_is_reproducible(ctx):
+    """chase_hip_hash64 (what the multi-rank tests compare instead of downloading replicas): equal content -> equal hash whatever
+    the leading dimension and however often it is computed; one flipped bit, two swapped entries or a sign of zero -> another"""
+    rng = np.random.default_rng(11)
+    for cplx in (False, True):
+        m, n = 1531, 37
+        A = rng.standard_normal((m, n)) + (1j * rng.standard_normal((m, n)) if cplx else 0)
+        dA = ctx.array(np.asfortranarray(A))
+        h0 = ctx.hash64(dA.ptr, m, n, m, cplx)
+        assert h0 != 0 and all(ctx.hash64(dA.ptr, m, n, m, cplx) == h0 for _ in range(5))
+        big = np.zeros((m + 9, n), dtype=A.dtype, order="F")
+        big[:m] = A
+        dB = ctx.array(big)
+        assert ctx.hash64(dB.ptr, m, n, m + 9, cplx) == h0                 # same content behind another leading dimension
+        for change in ("bit", "swap", "negzero"):
+            B = np.array(A, order="F")
+            if change == "bit":
+                v = B.view(np.uint64)
+                v[700, 3] ^= np.uint64(1)
+            elif change == "swap":
+                B[[10, 11], 5] = B[[11, 10], 5]
+            else:
+                B[0, 0] = 0.0
+                dZ = ctx.array(B)
+                hz = ctx.hash64(dZ.ptr, m, n, m, cplx)
+                B[0, 0] = -0.0 if not cplx else complex(-0.0, 0.0)
+                dC = ctx.array(B)
+                assert ctx.hash64(dC.ptr, m, n, m, cplx) != hz
+                continue
+            dC = ctx.array(B)
+            assert ctx.hash64(dC.ptr, m, n, m, cplx) != h0, change
+        assert ctx.hash64(dA.ptr, m, n - 1, m, cplx) != h0
