@@ -18,7 +18,7 @@ def pytest_configure(config):
 # Impl with ranks as threads - all inside this one process - and only then the tests that start other processes (ranks as
 # processes, bench.py), so that nothing a process-count limit of the box does to those can hide the parity evidence
 _ORDER = ["test_gpu_kernels", "test_gpu_solve", "test_gpu_pseudo", "test_gpu_reference_unit_tests", "test_gpu_dist",
-          "test_gpu_processes", "test_gpu_bench"]
+          "test_gpu_replay", "test_gpu_fullsize", "test_gpu_processes", "test_gpu_bench"]
 
 
 def pytest_collection_modifyitems(session, config, items):

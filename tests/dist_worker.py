@@ -2,7 +2,9 @@
 process per rank (the global solver objects of the C interface, the RCCL transport).  Everything else runs its ranks as
 threads of the pytest process (tests/rank_threads.py); the scenarios are shared (tests/dist_scenarios.py).
 
-usage: dist_worker.py <transport: host|rccl> <scenario> [args]   exit code 0 = all assertions passed on this rank."""
+usage: dist_worker.py <transport: host|rccl> <scenario> [args] [-- <scenario> [args] ...]
+Several scenarios separated by "--" run one after the other on the same context and grid (one process start-up, one set of RCCL
+communicators for all of them).  Exit code 0 = all assertions passed on this rank."""
 import os
 import sys
 
@@ -45,13 +47,23 @@ def setup(transport, nprow=None, npcol=None):
 
 
 def main():
-    transport, scen = sys.argv[1], sys.argv[2]
+    transport = sys.argv[1]
+    jobs, cur = [], []
+    for a in sys.argv[2:]:
+        if a == "--":
+            jobs.append(cur); cur = []
+        else:
+            cur.append(a)
+    jobs.append(cur)
     ctx, grid, comm = setup(transport)
     try:
-        S.run_named(scen, ctx, grid, comm, sys.argv[3:])
-        comm.barrier()
+        for job in jobs:
+            S.run_named(job[0], ctx, grid, comm, job[1:])
+            comm.barrier()
+            if comm.rank == 0:
+                print("DIST_WORKER_DONE", job[0], flush=True)
         if comm.rank == 0:
-            print("DIST_WORKER_OK", scen, flush=True)
+            print("DIST_WORKER_OK", " ".join(j[0] for j in jobs), flush=True)
     finally:
         grid.close()
         ctx.close()

@@ -711,8 +711,8 @@ def test_hash64_tells_blocks_apart_and_is_reproducible(ctx):
         for change in ("bit", "swap", "negzero"):
             B = np.array(A, order="F")
             if change == "bit":
-                v = B.view(np.uint64)
-                v[700, 3] ^= np.uint64(1)
+                v = B.reshape(-1, order="F").view(np.uint64)       # (a view: B is column-major)
+                v[3 * m * (2 if cplx else 1) + 700] ^= np.uint64(1)
             elif change == "swap":
                 B[[10, 11], 5] = B[[11, 10], 5]
             else:

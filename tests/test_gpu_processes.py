@@ -20,6 +20,13 @@ def run_ranks(nranks, transport, *args, timeout=600, env_extra=None):
     rendezvous store): a launcher process of its own would be one more process holding the GPU (it imports torch), and the box
     allows six - pytest + four ranks must stay below that."""
     assert nranks <= 4, "box limit: at most 6 processes with the GPU open, pytest itself is one of them"
+    # several scenarios (each a list / tuple) run one after the other inside ONE set of rank processes: a process start-up
+    # (python + torch + the HIP runtime + RCCL communicators) costs 5-8 s per rank, which used to be most of this file's time
+    if args and isinstance(args[0], (list, tuple)):
+        flat = []
+        for i, job in enumerate(args):
+            flat += (["--"] if i else []) + list(job)
+        args = tuple(flat)
     _PORT[0] += 1
     import tempfile
     procs, files = [], []
@@ -55,9 +62,7 @@ def test_rccl_forced_through_size1_communicators():
     ncclAllReduce, ncclBroadcast, the communication stream, the per-panel events of the pipelined HEMM (Hermitian and
     pseudo-Hermitian filter)."""
     force = {"CHASE_HIP_RCCL_FORCE": "1"}
-    run_ranks(1, "rccl", "solve", 1001, 100, 60, "z", 64, 20, env_extra=force)
-    run_ranks(1, "rccl", "ops", "d", 0, env_extra=force)
-    run_ranks(1, "rccl", "pseudo_solve", 0, env_extra=force)
+    run_ranks(1, "rccl", ["solve", 1001, 100, 60, "z", 64, 20], ["ops", "d", 0], ["pseudo_solve", 0], env_extra=force)
     run_ranks(1, "rccl", "pseudo_ops", 0, env_extra=force)
 
 
@@ -73,42 +78,30 @@ def test_real_rccl_collectives_between_two_ranks():
     collectives.  The 2 x 1 grid is where the first run found a real race (the row -> column product of a grid with ONE column
     did not wait for the column group's all-reduce of its input, pchase_hip_impl.hpp hemm_ptr) - invisible to the synchronous
     host transport and to size-1 communicators."""
-    run_ranks(2, "rccl", "p2p", env_extra=FAKE_HOSTS)
-    run_ranks(2, "rccl", "ops", "z", 16, env_extra=FAKE_HOSTS)
-    run_ranks(2, "rccl", "solve", 1001, 100, 60, "z", 64, 20, env_extra=FAKE_HOSTS)
-    run_ranks(2, "rccl", "pseudo_ops", 0, env_extra=FAKE_HOSTS)
-    run_ranks(2, "rccl", "pseudo_solve", 0, env_extra=FAKE_HOSTS)
-    run_ranks(2, "rccl", "qr_fixtures", "d", 0, env_extra=FAKE_HOSTS)
-    run_ranks(2, "rccl", "cshim", "z", 16, env_extra=FAKE_HOSTS)
+    run_ranks(2, "rccl", ["p2p"], ["ops", "z", 16], ["solve", 1001, 100, 60, "z", 64, 20], ["pseudo_ops", 0], ["pseudo_solve", 0],
+              ["qr_fixtures", "d", 0], ["cshim", "z", 16], env_extra=FAKE_HOSTS)
 
 
 def test_real_rccl_collectives_in_a_three_rank_column_group():
     """3 x 1: three-member communicators (RCCL's ring / tree with an odd member count), the K-conjugation partners two grid rows
     away, block-cyclic rows of the distributed Householder"""
-    run_ranks(3, "rccl", "ops", "z", 0, env_extra=FAKE_HOSTS)
-    run_ranks(3, "rccl", "pseudo_solve", 0, env_extra=FAKE_HOSTS)
-    run_ranks(3, "rccl", "qr_fixtures", "d", 16, env_extra=FAKE_HOSTS)
+    run_ranks(3, "rccl", ["ops", "z", 0], ["pseudo_solve", 0], ["qr_fixtures", "d", 16], env_extra=FAKE_HOSTS)
 
 
 def test_real_rccl_collectives_on_the_2x2_grid():
     """the same with four rank processes (row AND column communicators of two ranks each): operators, a block-cyclic solve
     whose eigenvector replicas must agree bit for bit across the two column communicators, the pseudo-Hermitian path, the
     distributed Householder QR"""
-    run_ranks(4, "rccl", "ops", "d", 0, env_extra=FAKE_HOSTS)
-    run_ranks(4, "rccl", "solve", 1001, 100, 60, "d", 64, 20, env_extra=FAKE_HOSTS)
-    # round 5: panel width / K-piece granularity / one-or-two communication streams switched between the iterations of a
-    # solve over REAL asynchronous collectives (what the first-contact self-tuning of bench.py --gpus N relies on)
-    run_ranks(4, "rccl", "knobs", 640, 40, 24, "z", 16, 20, env_extra=FAKE_HOSTS)
-    # round 5: symOrHermMatrix on the grid - two pairwise exchanges (ncclSend / ncclRecv) inside the column and row groups
-    run_ranks(4, "rccl", "sym_or_herm", "z", 16, env_extra=FAKE_HOSTS)
-    run_ranks(4, "rccl", "pseudo_solve", 0, env_extra=FAKE_HOSTS)
-    run_ranks(4, "rccl", "qr_fixtures", "z", 0, env_extra=FAKE_HOSTS)
+    # round 5 additions: "knobs" - panel width / K-piece granularity / one-or-two communication streams switched between the
+    # iterations of a solve over REAL asynchronous collectives (what the first-contact self-tuning of bench.py --gpus N relies
+    # on); "sym_or_herm" - symOrHermMatrix on the grid: two pairwise exchanges (ncclSend / ncclRecv) inside the groups
+    run_ranks(4, "rccl", ["ops", "d", 0], ["solve", 1001, 100, 60, "d", 64, 20], ["knobs", 640, 40, 24, "z", 16, 20],
+              ["sym_or_herm", "z", 16], ["pseudo_solve", 0], ["qr_fixtures", "z", 0], env_extra=FAKE_HOSTS)
 
 
 def test_four_processes_share_the_gpu_through_gloo():
     """ranks as processes on the torch.distributed (gloo) fabric: 2 x 2 block-cyclic operators + the C entry points"""
-    run_ranks(4, "host", "ops", "z", 16)
-    run_ranks(4, "host", "cshim", "d", 0)
+    run_ranks(4, "host", ["ops", "z", 16], ["cshim", "d", 0])
 
 
 def test_reference_mpi_signatures_on_one_rank():
