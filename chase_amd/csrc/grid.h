@@ -6,10 +6,17 @@
 #include "../../include/chase_hip_grid.h"
 #include "ctx.h"
 
+// In-process fabric of rank THREADS that share one device (chase_hip_fabric_create): the collectives of such ranks are device-side
+// sums / copies between the ranks' buffers, ordered by events between the ranks' streams - no host staging, no host
+// synchronisation.  Test plumbing like the host-callback transport (N ranks on ONE GPU), but asynchronous like RCCL.
+struct chase_hip_fabric;
+
 struct chase_hip_grid {
     chase_hip_ctx* ctx = nullptr;
     int nprow = 1, npcol = 1, rank = 0, myrow = 0, mycol = 0;
     bool use_rccl = false;
+    chase_hip_fabric* fabric = nullptr;               // shared-device transport (ranks = threads of this process on one GPU)
+    hipEvent_t fab_ready = nullptr, fab_done = nullptr;
     // loopback: a transport for ONE rank of a larger grid with nothing on the other side (single-rank replay of a
     // multi-GPU solve, bench.py --replay-rank): collectives keep their stream ordering, events and waits exactly as with
     // RCCL but enqueue no communication (optionally one read+write pass over the payload, loopback_touch: the HBM traffic a

@@ -30,6 +30,10 @@ using namespace chase_hip;
 // + write pass over the payload (touch: the HBM traffic a ring all-reduce causes on this device) and then stay resident until
 // `ticks` of the constant 100 MHz clock have passed since they started - the time the modelled collective would hold its
 // communication stream and its CUs (chase_hip_grid_set_loopback_model).
+static int fabric_collective(chase_hip_grid* g, int mode, int group, void* dev, size_t count, int root);
+static int fabric_sendrecv(chase_hip_grid* g, int group, const void* sendbuf, size_t sendcount, int peer_send, void* recvbuf,
+                           size_t recvcount, int peer_recv);
+
 // FOOTPRINT: an RCCL kernel is 512 threads per workgroup with up to 128 VGPRs per thread (its launch bounds) - eight such
 // waves do not fit on a CU beside the TWO workgroups of the MFMA GEMM (2 waves x ~250 VGPRs per SIMD), so a resident collective
 // workgroup costs the GEMM a workgroup slot.  The stand-in claims the same: 512 threads, v127 touched.
@@ -229,6 +233,8 @@ int chase_hip_grid_destroy(chase_hip_grid* g)
     for (int i = 0; i < 2; ++i)
         if (g->comm[i]) ncclCommDestroy(g->comm[i]);
     if (g->scal_dev) hipFree(g->scal_dev);
+    if (g->fab_ready) hipEventDestroy(g->fab_ready);
+    if (g->fab_done) hipEventDestroy(g->fab_done);
     for (int i = 0; i < 2; ++i)
         for (hipEvent_t e : g->slots[i])
             if (e) hipEventDestroy(e);
@@ -301,6 +307,7 @@ static int collective(chase_hip_grid* g, int mode, int group, void* dev, size_t 
         if (!async) return chase_hip_grid_wait(g);
         return 0;
     }
+    if (g->fabric) return fabric_collective(g, mode, group, dev, count, root);
     // host-callback transport: synchronous by construction
     const size_t bytes = count * sizeof(double);
     int rc = c->ensure_hstage(bytes);
@@ -455,6 +462,7 @@ int chase_hip_grid_sendrecv(chase_hip_grid* g, int group, const void* sendbuf, s
         g->pending[g->stream_index(group)] = true;
         return chase_hip_grid_wait(g);
     }
+    if (g->fabric) return fabric_sendrecv(g, group, sendbuf, sendcount, peer_send, recvbuf, recvcount, peer_recv);
     if (!g->h_sendrecv) return set_error(CHASE_HIP_ECOMM, "sendrecv: host transport has no send/recv callback");
     const size_t sb = (peer_send >= 0 ? sendcount : 0) * sizeof(double), rb = (peer_recv >= 0 ? recvcount : 0) * sizeof(double);
     int rc = c->ensure_hstage(sb + rb + 16);
@@ -496,7 +504,7 @@ int chase_hip_grid_comm_exposed_ms(chase_hip_grid* g, double* ms, unsigned long 
 int chase_hip_grid_transport(chase_hip_grid* g, int* is_rccl, int* row_ranks, int* col_ranks)
 {
     if (!g) return set_error(CHASE_HIP_EINVAL, "grid_transport: NULL grid");
-    if (is_rccl) *is_rccl = g->use_rccl ? 1 : (g->loopback ? 2 : 0);   /* 0 host callbacks, 1 RCCL, 2 loopback */
+    if (is_rccl) *is_rccl = g->use_rccl ? 1 : (g->loopback ? 2 : (g->fabric ? 3 : 0));   /* 0 host callbacks, 1 RCCL, 2 loopback, 3 shared device */
     int n[2] = {1, 1};
     for (int i = 0; i < 2; ++i) {
         if (g->use_rccl && g->comm[i]) NCCLCHK(ncclCommCount(g->comm[i], &n[i]));
@@ -528,5 +536,239 @@ long chase_hip_numroc(long n, long nb, int iproc, int nprocs)
 int chase_hip_owner(long g, long nb, int nprocs) { return (int)((g / nb) % nprocs); }
 long chase_hip_local_index(long g, long nb, int nprocs) { return (g / (nb * nprocs)) * nb + g % nb; }
 long chase_hip_global_index(long l, long nb, int iproc, int nprocs) { return ((l / nb) * nprocs + iproc) * nb + l % nb; }
+
+} // extern "C"
+
+/* ================= shared-device transport: ranks = threads of ONE process on ONE device ==============================
+ * (chase_hip_grid.h: chase_hip_fabric_create / chase_hip_grid_create_shared).  A group's all-reduce: every member publishes
+ * its buffer and an event on its stream; member 0 sums the buffers in member order into the group's scratch (one kernel,
+ * fixed order: every member gets the same bits); every member copies the sum into its buffer on its own stream.  Nothing
+ * waits on the host except the threads' rendezvous (condition variables with a time-out; a failed rank aborts the fabric
+ * and everybody returns CHASE_HIP_ECOMM instead of waiting). */
+#include <chrono>
+#include <condition_variable>
+#include <map>
+#include <mutex>
+
+namespace {
+constexpr int FAB_MAX = 16;
+struct FabPtrs { const double* p[FAB_MAX]; int n; };
+__global__ __launch_bounds__(256) void fabric_sum_kernel(FabPtrs src, double* __restrict__ out, size_t count)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        double s = src.p[0][i];
+        for (int k = 1; k < src.n; ++k) s += src.p[k][i];
+        out[i] = s;
+    }
+}
+struct FabBox {                       // one direction of a pair inside a group (send/recv)
+    const void* ptr = nullptr; size_t count = 0;
+    unsigned long posted = 0, taken = 0;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+};
+struct FabGroup {
+    int size = 1;
+    int arrived = 0;
+    unsigned long gen = 0;
+    std::vector<void*> ptr;
+    std::vector<hipEvent_t> ev_ready, ev_done;        // owned by the members' grids
+    void* scratch = nullptr; size_t scratch_bytes = 0;
+    hipEvent_t ev_sum = nullptr;
+    std::map<std::pair<int, int>, FabBox> box;        // (from, to)
+};
+} // namespace
+
+struct chase_hip_fabric {
+    int nprow = 1, npcol = 1, device = -1;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool failed = false;
+    double timeout_s = 600.0;
+    std::vector<FabGroup> row, col;                   // row[myrow] has npcol members, col[mycol] has nprow members
+    FabGroup& group(int g, int myrow, int mycol) { return g == CHASE_HIP_ROW ? row[myrow] : col[mycol]; }
+    // rendezvous of a group's members; returns false on abort / time-out
+    bool barrier(FabGroup& G)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (failed) return false;
+        const unsigned long my_gen = G.gen;
+        if (++G.arrived == G.size) { G.arrived = 0; ++G.gen; cv.notify_all(); return true; }
+        const bool ok = cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return failed || G.gen != my_gen; });
+        if (!ok) { failed = true; cv.notify_all(); }
+        return ok && !failed;
+    }
+};
+
+static int fab_fail(const char* what) { return set_error(CHASE_HIP_ECOMM, what); }
+
+static int fabric_collective(chase_hip_grid* g, int mode, int group, void* dev, size_t count, int root)
+{
+    chase_hip_fabric* F = g->fabric;
+    chase_hip_ctx* c = g->ctx;
+    FabGroup& G = F->group(group, g->myrow, g->mycol);
+    const int me = g->group_rank(group), p = G.size;
+    hipStream_t st = c->stream;
+    const size_t bytes = count * sizeof(double);
+    // 1. publish my buffer and the point of my stream it is ready at
+    HIPCHK(hipEventRecord(g->fab_ready, st));
+    { std::lock_guard<std::mutex> lk(F->mu); G.ptr[me] = dev; G.ev_ready[me] = g->fab_ready; G.ev_done[me] = g->fab_done; }
+    if (!F->barrier(G)) return fab_fail("shared transport: a rank failed or timed out (publish)");
+    if (mode == 0) {
+        if (me == 0) {
+            // the scratch is free once every member's previous copy out of it has run (their ev_done of the previous round)
+            for (int k = 0; k < p; ++k) HIPCHK(hipStreamWaitEvent(st, G.ev_done[k], 0));
+            if (G.scratch_bytes < bytes) {
+                HIPCHK(hipStreamSynchronize(st));
+                if (G.scratch) HIPCHK(hipFree(G.scratch));
+                G.scratch = nullptr; G.scratch_bytes = 0;
+                HIPCHK(hipMalloc(&G.scratch, bytes));
+                G.scratch_bytes = bytes;
+            }
+            FabPtrs src; src.n = p;
+            for (int k = 0; k < p; ++k) { HIPCHK(hipStreamWaitEvent(st, G.ev_ready[k], 0)); src.p[k] = (const double*)G.ptr[k]; }
+            const unsigned blocks = (unsigned)std::min<size_t>(2048, (count + 255) / 256);
+            hipLaunchKernelGGL(fabric_sum_kernel, dim3(blocks), dim3(256), 0, st, src, (double*)G.scratch, count);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(G.ev_sum, st));
+        }
+        if (!F->barrier(G)) return fab_fail("shared transport: a rank failed or timed out (sum)");
+        HIPCHK(hipStreamWaitEvent(st, G.ev_sum, 0));
+        HIPCHK(hipMemcpyAsync(dev, G.scratch, bytes, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipEventRecord(g->fab_done, st));
+        if (!F->barrier(G)) return fab_fail("shared transport: a rank failed or timed out (copy)");
+        return 0;
+    }
+    // broadcast: everybody copies the root's buffer; the root must not touch it again before the copies have run
+    if (me != root) {
+        HIPCHK(hipStreamWaitEvent(st, G.ev_ready[root], 0));
+        HIPCHK(hipMemcpyAsync(dev, G.ptr[root], bytes, hipMemcpyDeviceToDevice, st));
+    }
+    HIPCHK(hipEventRecord(g->fab_done, st));
+    if (!F->barrier(G)) return fab_fail("shared transport: a rank failed or timed out (broadcast)");
+    if (me == root)
+        for (int k = 0; k < p; ++k)
+            if (k != root) HIPCHK(hipStreamWaitEvent(st, G.ev_done[k], 0));
+    // (the members' ev_done now mean "broadcast copied", which also satisfies the next all-reduce's scratch wait)
+    return 0;
+}
+
+static int fabric_sendrecv(chase_hip_grid* g, int group, const void* sendbuf, size_t sendcount, int peer_send, void* recvbuf,
+                           size_t recvcount, int peer_recv)
+{
+    chase_hip_fabric* F = g->fabric;
+    FabGroup& G = F->group(group, g->myrow, g->mycol);
+    const int me = g->group_rank(group);
+    hipStream_t st = g->ctx->stream;
+    FabBox* out = nullptr;
+    if (peer_send >= 0) {
+        std::unique_lock<std::mutex> lk(F->mu);
+        out = &G.box[{me, peer_send}];
+        if (!out->ev_ready) {
+            lk.unlock();
+            hipEvent_t a = nullptr, b = nullptr;
+            HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+            lk.lock();
+            out->ev_ready = a; out->ev_done = b;
+        }
+        hipEvent_t ready = out->ev_ready;
+        lk.unlock();
+        HIPCHK(hipEventRecord(ready, st));
+        lk.lock();
+        out->ptr = sendbuf; out->count = sendcount; ++out->posted;
+        F->cv.notify_all();
+    }
+    if (peer_recv >= 0) {
+        std::unique_lock<std::mutex> lk(F->mu);
+        FabBox& in = G.box[{peer_recv, me}];
+        const bool ok = F->cv.wait_for(lk, std::chrono::duration<double>(F->timeout_s), [&] { return F->failed || in.posted > in.taken; });
+        if (!ok || F->failed) { F->failed = true; F->cv.notify_all(); return fab_fail("shared transport: peer never sent"); }
+        if (in.count != recvcount) { F->failed = true; F->cv.notify_all(); return fab_fail("shared transport: send / receive counts differ"); }
+        const void* src = in.ptr; hipEvent_t ready = in.ev_ready, done = in.ev_done;
+        lk.unlock();
+        HIPCHK(hipStreamWaitEvent(st, ready, 0));
+        HIPCHK(hipMemcpyAsync(recvbuf, src, recvcount * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipEventRecord(done, st));
+        lk.lock();
+        ++in.taken;
+        F->cv.notify_all();
+    }
+    if (out) {
+        std::unique_lock<std::mutex> lk(F->mu);
+        const bool ok = F->cv.wait_for(lk, std::chrono::duration<double>(F->timeout_s), [&] { return F->failed || out->taken == out->posted; });
+        if (!ok || F->failed) { F->failed = true; F->cv.notify_all(); return fab_fail("shared transport: peer never received"); }
+        hipEvent_t done = out->ev_done;
+        lk.unlock();
+        HIPCHK(hipStreamWaitEvent(st, done, 0));               // my send buffer is free again once the peer's copy has run
+    }
+    return 0;
+}
+
+extern "C" {
+
+int chase_hip_fabric_create(chase_hip_fabric** out, int nprow, int npcol)
+{
+    if (!out || nprow < 1 || npcol < 1 || nprow > FAB_MAX || npcol > FAB_MAX) return set_error(CHASE_HIP_EINVAL, "fabric_create: bad grid");
+    chase_hip_fabric* F = new chase_hip_fabric();
+    F->nprow = nprow; F->npcol = npcol;
+    F->row.resize(nprow); F->col.resize(npcol);
+    for (auto& G : F->row) { G.size = npcol; G.ptr.assign(npcol, nullptr); G.ev_ready.assign(npcol, nullptr); G.ev_done.assign(npcol, nullptr); }
+    for (auto& G : F->col) { G.size = nprow; G.ptr.assign(nprow, nullptr); G.ev_ready.assign(nprow, nullptr); G.ev_done.assign(nprow, nullptr); }
+    if (const char* e = getenv("CHASE_HIP_FABRIC_TIMEOUT_S")) F->timeout_s = atof(e);
+    *out = F;
+    return 0;
+}
+/* a rank failed: every thread waiting in the fabric (and every later call) returns CHASE_HIP_ECOMM */
+int chase_hip_fabric_abort(chase_hip_fabric* F)
+{
+    if (!F) return 0;
+    std::lock_guard<std::mutex> lk(F->mu);
+    F->failed = true;
+    F->cv.notify_all();
+    return 0;
+}
+/* after every grid on it is destroyed */
+int chase_hip_fabric_destroy(chase_hip_fabric* F)
+{
+    if (!F) return 0;
+    if (F->device >= 0) (void)hipSetDevice(F->device);
+    for (auto* v : {&F->row, &F->col})
+        for (auto& G : *v) {
+            if (G.scratch) (void)hipFree(G.scratch);
+            if (G.ev_sum) (void)hipEventDestroy(G.ev_sum);
+            for (auto& kv : G.box) { if (kv.second.ev_ready) (void)hipEventDestroy(kv.second.ev_ready); if (kv.second.ev_done) (void)hipEventDestroy(kv.second.ev_done); }
+        }
+    delete F;
+    return 0;
+}
+
+int chase_hip_grid_create_shared(chase_hip_grid** out, chase_hip_ctx* ctx, int nprow, int npcol, int rank, chase_hip_fabric* F)
+{
+    if (!out || !F) return set_error(CHASE_HIP_EINVAL, "grid_create_shared: NULL argument");
+    if (F->nprow != nprow || F->npcol != npcol) return set_error(CHASE_HIP_EINVAL, "grid_create_shared: the fabric is for another grid");
+    chase_hip_grid* g = new chase_hip_grid();
+    int rc = grid_common(g, ctx, nprow, npcol, rank);
+    if (rc) { chase_hip_grid_destroy(g); return rc; }
+    g->fabric = F;
+    rc = [&]() -> int {
+        HIPCHK(hipEventCreateWithFlags(&g->fab_ready, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&g->fab_done, hipEventDisableTiming));
+        std::lock_guard<std::mutex> lk(F->mu);
+        if (F->device >= 0 && F->device != ctx->device) return set_error(CHASE_HIP_EINVAL, "grid_create_shared: the ranks of a fabric share ONE device");
+        F->device = ctx->device;
+        for (int grp : {CHASE_HIP_ROW, CHASE_HIP_COL}) {
+            FabGroup& G = F->group(grp, g->myrow, g->mycol);
+            if (!G.ev_sum) HIPCHK(hipEventCreateWithFlags(&G.ev_sum, hipEventDisableTiming));
+            const int me = g->group_rank(grp);
+            G.ev_ready[me] = g->fab_ready; G.ev_done[me] = g->fab_done;
+        }
+        return 0;
+    }();
+    if (rc) { chase_hip_grid_destroy(g); return rc; }
+    // every member's events must exist before anybody waits on them: the first collective's publish rendezvous orders that
+    *out = g;
+    return 0;
+}
 
 } // extern "C"

@@ -14,6 +14,10 @@ AR_FN = C.CFUNCTYPE(c_int, c_void_p, c_int, P(c_double), c_size_t)
 BC_FN = C.CFUNCTYPE(c_int, c_void_p, c_int, P(c_double), c_size_t, c_int)
 _sig("chase_hip_grid_create_host", c_int, P(c_void_p), c_void_p, c_int, c_int, c_int, AR_FN, BC_FN, c_void_p)
 _sig("chase_hip_grid_create_loopback", c_int, P(c_void_p), c_void_p, c_int, c_int, c_int)
+_sig("chase_hip_fabric_create", c_int, P(c_void_p), c_int, c_int)
+_sig("chase_hip_fabric_abort", c_int, c_void_p)
+_sig("chase_hip_fabric_destroy", c_int, c_void_p)
+_sig("chase_hip_grid_create_shared", c_int, P(c_void_p), c_void_p, c_int, c_int, c_int, c_void_p)
 _sig("chase_hip_grid_set_loopback_model", c_int, c_void_p, c_double, c_double, c_int, c_int)
 _sig("chase_hip_grid_set_comm_streams", c_int, c_void_p, c_int)
 _sig("chase_hip_grid_comm_streams", c_int, c_void_p)
@@ -147,6 +151,13 @@ class Grid:
                 ids2 = [bytes(my_id2.raw)]
             check(lib.chase_hip_grid_create_rccl(C.byref(h), ctx.h, nprow, npcol, rank, ids[row_leader],
                                                  ids2[col_leader]), "grid_create_rccl")
+        elif transport == "shared":
+            # ranks = threads of this process sharing ONE device: device-side collectives through the fabric object the
+            # communicator carries (chase_amd.rank_threads.run_ranks(transport="shared") creates it before the threads start)
+            fabric = getattr(getattr(pg, "w", None), "fabric", None)
+            if not fabric:
+                raise ValueError("transport 'shared' needs the rank threads' fabric (rank_threads.run_ranks)")
+            check(lib.chase_hip_grid_create_shared(C.byref(h), ctx.h, nprow, npcol, rank, fabric), "grid_create_shared")
         elif transport == "loopback":
             # ONE rank of the grid with nobody on the other side (single-rank replay, chase_hip_grid_create_loopback)
             check(lib.chase_hip_grid_create_loopback(C.byref(h), ctx.h, nprow, npcol, rank), "grid_create_loopback")

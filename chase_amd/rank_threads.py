@@ -25,8 +25,16 @@ TIMEOUT = 600.0
 
 
 class _World:
-    def __init__(self, nprow, npcol):
+    def __init__(self, nprow, npcol, shared_device_fabric=False):
         self.nprow, self.npcol, self.n = nprow, npcol, nprow * npcol
+        self.fabric = None                     # chase_hip_fabric* of the shared-device transport (ranks on ONE GPU, no host staging)
+        if shared_device_fabric:
+            import ctypes
+            from chase_amd.capi import lib, check
+            from chase_amd import dist as _cd  # noqa: F401  (declares the fabric entry points)
+            f = ctypes.c_void_p()
+            check(lib.chase_hip_fabric_create(ctypes.byref(f), nprow, npcol), "fabric_create")
+            self.fabric = f
         self.failed = threading.Event()
         self.world_barrier = threading.Barrier(self.n)
         # group id: (ROW, myrow) has npcol members, (COL, mycol) has nprow members
@@ -46,6 +54,9 @@ class _World:
 
     def abort(self):
         self.failed.set()
+        if self.fabric:
+            from chase_amd.capi import lib
+            lib.chase_hip_fabric_abort(self.fabric)          # ranks waiting inside a device-side collective return an error
         self.world_barrier.abort()
         for b in self.group_barrier.values():
             b.abort()
@@ -149,10 +160,10 @@ class RankComm:
                         raise RuntimeError("sendrecv: peer never sent (another rank failed or timed out)")
 
 
-def run_threads(nprow, npcol, body):
+def run_threads(nprow, npcol, body, shared_device_fabric=False):
     """body(comm) on nprow*npcol threads; re-raises the first failure in the caller (a failing rank breaks every barrier, so
     the others fail fast instead of waiting for it)."""
-    world = _World(nprow, npcol)
+    world = _World(nprow, npcol, shared_device_fabric)
     errors = [None] * world.n
 
     def wrapped(rank):
@@ -170,6 +181,10 @@ def run_threads(nprow, npcol, body):
     for t in threads:
         t.join(TIMEOUT + 60)
     alive = [t.name for t in threads if t.is_alive()]
+    if world.fabric and not alive:
+        from chase_amd.capi import lib
+        lib.chase_hip_fabric_destroy(world.fabric)           # every grid on it is closed (run_ranks closes them in `finally`)
+        world.fabric = None
     # the FIRST failure in time is the cause; the ranks that then found their barriers broken (directly, or as a failed
     # transport callback inside the library) are consequences
     failed = sorted(((e[2], r, e) for r, e in enumerate(errors) if e), key=lambda t: t[0])
@@ -182,7 +197,8 @@ def run_threads(nprow, npcol, body):
 def run_ranks(nprow, npcol, fn, *args, device=0, transport="host", **kw):
     """Runs fn(ctx, grid, comm, *args, **kw) on nprow*npcol rank threads, each with its own Context and Grid.  device: one
     ordinal for all ranks (tests: the ranks share a GPU over the host transport) or a callable rank -> ordinal
-    (`bench.py --ranks threads`: one GPU per thread, transport "rccl")."""
+    (`bench.py --ranks threads`: one GPU per thread, transport "rccl").  transport "shared": the ranks share ONE GPU and their
+    collectives are device-side sums / copies ordered by events (chase_hip_grid_create_shared) - no host staging."""
     from chase_amd.capi import Context
     from chase_amd import dist as cd
 
@@ -198,7 +214,7 @@ def run_ranks(nprow, npcol, fn, *args, device=0, transport="host", **kw):
             if ctx is not None:
                 ctx.close()
 
-    run_threads(nprow, npcol, body)
+    run_threads(nprow, npcol, body, shared_device_fabric=(transport == "shared"))
 
 
 class GlooComm:

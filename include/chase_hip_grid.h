@@ -51,6 +51,16 @@ int chase_hip_grid_create_loopback(chase_hip_grid** out, chase_hip_ctx* ctx, int
  * pass over the payload.  0 GB/s = nothing enqueued.  A stated MODEL for exercising the overlap machinery of the replayed
  * rank, never a measurement of xGMI (env: CHASE_HIP_LOOPBACK_BUSBW_GBPS / _LATENCY_US / _TOUCH / _WGS). */
 int chase_hip_grid_set_loopback_model(chase_hip_grid* g, double busbw_GBps, double latency_us, int touch, int workgroups);
+/* Shared-device transport (test plumbing, like the host callbacks): the ranks are THREADS of one process that share ONE device;
+ * a group's all-reduce is a device-side sum of the members' buffers in member order (every member gets the same bits), a
+ * broadcast / send-recv a device-to-device copy, all ordered by events between the ranks' streams - no host staging, no host
+ * synchronisation.  One fabric object per grid, created before the rank threads start; a failing rank aborts it, and every
+ * rank waiting in a collective returns CHASE_HIP_ECOMM instead of hanging (CHASE_HIP_FABRIC_TIMEOUT_S, default 600). */
+typedef struct chase_hip_fabric chase_hip_fabric;
+int chase_hip_fabric_create(chase_hip_fabric** out, int nprow, int npcol);
+int chase_hip_fabric_abort(chase_hip_fabric* f);
+int chase_hip_fabric_destroy(chase_hip_fabric* f);
+int chase_hip_grid_create_shared(chase_hip_grid** out, chase_hip_ctx* ctx, int nprow, int npcol, int rank, chase_hip_fabric* f);
 int chase_hip_grid_destroy(chase_hip_grid* g);
 /* communication streams: 2 (default) = one per group - on a 4 x 2 grid the row and column communicators use disjoint xGMI
  * links, so their collectives do not queue behind each other; 1 = both groups on one stream (CHASE_HIP_COMM_STREAMS=1).
@@ -85,7 +95,7 @@ int chase_hip_grid_set_host_sendrecv(chase_hip_grid* g, chase_hip_host_sendrecv_
  * else to run (synchronises the context stream), and the number of waits */
 int chase_hip_grid_set_profiling(chase_hip_grid* g, int on);
 int chase_hip_grid_comm_exposed_ms(chase_hip_grid* g, double* ms, unsigned long long* waits, int reset);
-/* which transport the grid runs on (*is_rccl: 0 host callbacks, 1 RCCL, 2 loopback) and how many ranks RCCL itself reports for this rank's row / column communicator
+/* which transport the grid runs on (*is_rccl: 0 host callbacks, 1 RCCL, 2 loopback, 3 shared device) and how many ranks RCCL itself reports for this rank's row / column communicator
  * (ncclCommCount; 1 for a group without communicator) */
 int chase_hip_grid_transport(chase_hip_grid* g, int* is_rccl, int* row_ranks, int* col_ranks);
 

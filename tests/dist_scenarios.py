@@ -756,6 +756,15 @@ def scenario_p2p(ctx, grid, comm):
     assert lib.chase_hip_grid_agree_max(grid.h, C.byref(v)) == 0 and v.value == world      # a real max, not a mean
     is_rccl, r, c = grid.transport_info()
     assert (r, c) == ((grid.npcol, grid.nprow) if not is_rccl or os.environ.get("CHASE_HIP_RCCL_FORCE") else (1, 1)) or is_rccl
+    # every member of a group gets the SAME bits from an all-reduce (what keeps replicas identical): random data, both groups
+    for group in (cd.ROW, cd.COL):
+        x = ctx.array(np.random.default_rng(rank).standard_normal((5003, 1)))
+        assert lib.chase_hip_grid_allreduce(grid.h, group, C.c_void_p(x.ptr), 5003, 0) == 0
+        got = x.download()
+        everyone = comm.all_gather_object((grid.myrow, grid.mycol, got))
+        for (i, j, other) in everyone:
+            if (group == cd.ROW and i == grid.myrow) or (group == cd.COL and j == grid.mycol):
+                assert np.array_equal(other, got)
 
 
 

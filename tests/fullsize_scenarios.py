@@ -73,7 +73,8 @@ def fullsize_rank(ctx, grid, comm, wl, nb, result, hash_replicas=True):
         for (i, j, _, _, dg, _) in everyone:
             rows.setdefault(i, set()).add(dg)
         result.update(workload=wl, grid=f"{nprow}x{npcol}", nb=nb, N=N, nev=nev, nex=nex,
-                      transport="host callbacks, ranks = threads of one process, ONE GPU",
+                      transport=("device-side collectives between the rank threads' buffers (shared-device transport), ONE GPU"
+                                 if grid.transport == "shared" else "host callbacks, ranks = threads of one process, ONE GPU"),
                       iterations=st["iterations"], filtered_vecs=st["filtered_vecs"], locked=st["locked"],
                       wall_seconds=wall, max_resid=float(np.max(resid)),
                       max_resid_recomputed=float(np.max(worst_re)), tol=tol,
@@ -92,8 +93,11 @@ def fullsize_rank(ctx, grid, comm, wl, nb, result, hash_replicas=True):
     del dH
 
 
-def run_fullsize(wl, nprow, npcol, nb, hash_replicas=True):
+def run_fullsize(wl, nprow, npcol, nb, hash_replicas=True, transport="shared"):
+    """transport "shared" (round 5): the rank threads' collectives are device-side sums / copies ordered by events between their
+    streams (chase_hip_grid_create_shared) - asynchronous like RCCL; "host": staged through pinned host memory into the Python
+    fabric (rounds 3-4; a fifth of the full-size wall time was that staging)"""
     from rank_threads import run_ranks
     result = {}
-    run_ranks(nprow, npcol, fullsize_rank, wl, nb, result, hash_replicas)
+    run_ranks(nprow, npcol, fullsize_rank, wl, nb, result, hash_replicas, transport=transport)
     return result

@@ -22,6 +22,12 @@ def run(nranks, fn, *args):
     run_ranks(*GRIDS[nranks], fn, *args)
 
 
+def run_shared(nranks, fn, *args):
+    """the same ranks-as-threads on the SHARED-DEVICE transport: device-side sums / copies between the ranks' buffers ordered by
+    events between their streams (chase_hip_grid_create_shared) - asynchronous like RCCL, no host staging"""
+    run_ranks(*GRIDS[nranks], fn, *args, transport="shared")
+
+
 @pytest.mark.parametrize("nranks", [2, 4])
 def test_hemm_known_answer(nranks):
     run(nranks, S.scenario_hemm_kat)
@@ -241,3 +247,43 @@ def test_c_interface_reinit_from_another_thread_replaces_the_solver(ctx):
     lib.chase_hip_cshim_dist_solver.restype = C.c_void_p
     assert flag.value == 0 and not lib.chase_hip_cshim_dist_solver(0)
     grid.close()
+
+
+# ---- the shared-device transport (ranks = threads on ONE GPU, device-side collectives): what the full-size tests run on -------
+def test_shared_device_transport_operators_and_exchanges():
+    run_shared(4, S.scenario_hemm_kat)
+    run_shared(4, S.scenario_p2p)
+    run_shared(6, S.scenario_p2p)
+    run_shared(4, S.scenario_ops, True, 16)
+    run_shared(8, S.scenario_ops, False, 0)
+    run_shared(6, S.scenario_sym_or_herm, True, 16)
+
+
+def test_shared_device_transport_solves():
+    run_shared(4, S.scenario_solve, 1001, 100, 60, False, 64, 20)
+    run_shared(8, S.scenario_solve_counts, 600, 40, 24, True, 16, 20)
+    run_shared(4, S.scenario_pseudo_solve, 0)
+    run_shared(6, S.scenario_qr_fixtures, True, 16)
+    run_shared(2, S.scenario_knob_switching, 640, 40, 24, True, 16, 20)
+
+
+def test_shared_device_transport_releases_the_ranks_when_one_fails():
+    """a rank that fails between collectives aborts the fabric: the others, waiting inside a device-side collective, come back
+    with an error instead of waiting for the time-out"""
+    import time
+    import numpy as np
+    from chase_amd.capi import lib, ChaseHipError, check
+    from chase_amd import dist as cd
+
+    def body(ctx, grid, comm):
+        d = ctx.array(np.ones(1000))
+        check(lib.chase_hip_grid_allreduce(grid.h, cd.COL, d.ptr, 1000, 0), "allreduce")
+        assert np.all(d.download() == grid.nprow)
+        if comm.rank == 1:
+            raise ValueError("rank 1 gives up")
+        check(lib.chase_hip_grid_allreduce(grid.h, cd.COL, d.ptr, 1000, 0), "allreduce")
+
+    t = time.time()
+    with pytest.raises(AssertionError, match="rank 1 gives up"):
+        run_ranks(2, 1, body, transport="shared")
+    assert time.time() - t < 60
