@@ -390,6 +390,25 @@ def attach_traffic(out, workload):
             pass
 
 
+def attach_replay(out, workload):
+    """The compute side of the multi-GPU solve as measured by the single-rank replay (bench.py --replay-rank, a SEPARATE run on
+    one GPU, recorded in profiles/): T_rank per grid and the speed-up bound it implies.  Context for the scaling series this
+    line starts; not measured in this run and labelled so."""
+    path = os.path.join(ROOT, "profiles", "r05_replay_cfg4.json")
+    if workload != "cfg4" or not os.path.exists(path):
+        return
+    try:
+        rec = json.load(open(path))
+        out["multi_gpu_compute_side"] = {
+            "source": "profiles/r05_replay_cfg4.json: `bench.py --replay-rank 4x2,2x2,2x1` - ONE rank of each grid replaying the "
+                      "taped call sequence of a real single-GPU solve on a loopback grid (no communication), NOT measured in this run",
+            "single_gpu_solve_seconds": rec["single_gpu"]["solve_seconds"],
+            "T_rank_seconds": {r["grid"]: r["T_rank_seconds"] for r in rec["replays"]},
+            "speedup_bound": {r["grid"]: r["compute_side_speedup_bound"] for r in rec["replays"]}}
+    except Exception:
+        pass
+
+
 def run_single(args):
     from chase_amd.capi import Context, Solver, gemm_counters
     N, cplx, nev, nex = WORKLOADS[args.workload]
@@ -456,6 +475,7 @@ def run_single(args):
     }
     out["roofline"]["whole_run"] = whole_run_object(snapshot(), 1)
     attach_traffic(out, args.workload)
+    attach_replay(out, args.workload)
     if not args.no_probe and cplx:
         # reference arithmetic (four real products per complex product, the reference's zgemm) on the same launch shape
         out["roofline_4m"] = fullwidth_probe(s, ctx, N, cplx, nevex, three_m=False)

@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <cstdio>
 #include <cstring>
 #include <limits>
 #include <random>
@@ -36,6 +37,7 @@
 #include "../../include/chase_hip_grid.h"
 #include "chase_hip_impl.hpp"
 #include "interface.hpp"
+#include "panel_pipeline.hpp"
 #include "roctx.hpp"
 
 namespace chase_amd {
@@ -299,6 +301,7 @@ public:
     std::size_t panel_cols() const { return panel_; }
     void set_panel_rounds(int r) { if (r < 0 || r > 16) throw std::invalid_argument("panel_rounds: 0..16"); panel_rounds_ = r; }
     int panel_rounds() const { return panel_rounds_; }
+    double last_ortho_check() const { return last_ortho_; }          // CHASE_QR_CHECK_ORTHO: ||Q^H Q - I||_inf of the last Householder QR
 
     // ---- life cycle ----------------------------------------------------------------------------------------------------
     void Start() override { locked_ = 0; }
@@ -789,22 +792,22 @@ protected:
             RoundsGuard(chase_hip_ctx* c, int r) : ctx(c) { if (c) chase_hip_ctx_set_gemm_min_rounds(c, r); }
             ~RoundsGuard() { if (ctx) chase_hip_ctx_set_gemm_min_rounds(ctx, 0); }
         } rounds_guard(pipe ? ctx_ : nullptr, panel_rounds);
-        std::size_t c = c0;
-        while (c < c0 + nc) {
-            const std::size_t fp = c / panel_;                                 // fixed panel index
-            const std::size_t cend = pipe ? std::min(c0 + nc, (fp + 1) * panel_) : c0 + nc;
-            const std::size_t w = cend - c;
-            if (pipe) coll(chase_hip_grid_event_wait(grid_, (int)fp));         // previous step's all-reduce of my input
-            if (bAc) gemm('C', n_, w, m_, alpha, Hb, ldb, in + c * in_ld, in_ld, b, out + c * out_ld, out_ld);
-            else     gemm('N', m_, w, n_, alpha, Hb, ldb, in + c * in_ld, in_ld, b, out + c * out_ld, out_ld);
-            if (active) {
-                coll(chase_hip_grid_allreduce(grid_, group, out + c * out_ld, out_ld * w * E, pipe ? 1 : 0));
-                // (an inactive direction records nothing: its output panel is ordered by the compute stream itself, and the
-                // slot keeps the other direction's last event, which this product has already waited for)
-                if (pipe) coll(chase_hip_grid_event_record_on(grid_, group, (int)fp));
+        // the ordering itself lives in panel_pipeline.hpp (and is checked on the CPU against a simulator of streams and events)
+        struct Ops {
+            pChaseHip* k; bool bAc; int group; T alpha, b; const T* Hb; std::size_t ldb; T* in; std::size_t in_ld; T* out; std::size_t out_ld;
+            void event_wait(int slot) { coll(chase_hip_grid_event_wait(k->grid_, slot)); }
+            void product(std::size_t c, std::size_t w)
+            {
+                if (bAc) k->gemm('C', k->n_, w, k->m_, alpha, Hb, ldb, in + c * in_ld, in_ld, b, out + c * out_ld, out_ld);
+                else     k->gemm('N', k->m_, w, k->n_, alpha, Hb, ldb, in + c * in_ld, in_ld, b, out + c * out_ld, out_ld);
             }
-            c = cend;
-        }
+            void allreduce(std::size_t c, std::size_t w, bool async)
+            {
+                coll(chase_hip_grid_allreduce(k->grid_, group, out + c * out_ld, out_ld * w * E, async ? 1 : 0));
+            }
+            void event_record(int grp, int slot) { coll(chase_hip_grid_event_record_on(k->grid_, grp, slot)); }
+        } ops{this, bAc, group, alpha, b, Hb, ldb, in, in_ld, out, out_ld};
+        pipelined_product(ops, pipe, active, group, c0, nc, panel_);
     }
     // X <- S X on the local rows of a column-type / row-type block (global rows >= N/2 change sign)
     void flip_coltype(T* X, std::size_t ncols, double s = -1.0)
@@ -894,8 +897,30 @@ protected:
         long off = 0;
         for (int q = 0; q < myrow_; ++q) off += Rr_.count(q);
         coll(chase_hip_houseqr_dist(ctx_, grid_, CHASE_HIP_COL, CP, (int)m_, (int)nc_, dV1_, (long)m_, off));
+        // CHASE_QR_CHECK_ORTHO=1 (the reference's diagnostic, linalg/internal/nccl/householder_qr.hpp:214-221,292-372): after the
+        // Householder path ||Q^H Q - I||_inf of the distributed Q is computed (Gram matrix, all-reduce over the column group) and
+        // reported by the group's first rank; last_ortho_check() returns it
+        if (const char* e = std::getenv("CHASE_QR_CHECK_ORTHO")) {
+            const std::string v(e);
+            if (v == "1" || v == "true" || v == "TRUE" || v == "on" || v == "ON") {
+                const std::size_t n = nc_;
+                hip_ok(chase_hip_herk(ctx_, CP, (int)n, (int)m_, dV1_, (long)m_, dA_, (long)n), "herk");
+                allreduce_packed_upper(dA_, n, CHASE_HIP_COL);
+                std::vector<T> G(n * n);
+                hip_ok(chase_hip_download_matrix(ctx_, CP, (int)n, (int)n, dA_, (long)n, G.data(), (long)n), "download");
+                double inf = 0;
+                for (std::size_t i = 0; i < n; ++i) {
+                    double row = 0;
+                    for (std::size_t j = 0; j < n; ++j) row += std::abs(G[i + j * n] - (i == j ? T(1) : T(0)));
+                    inf = std::max(inf, row);
+                }
+                last_ortho_ = inf;
+                if (myrow_ == 0)
+                    std::fprintf(stderr, "[ORTHO] ||Q^H Q - I||_inf = %.6e (ncols=%zu, l_rows=%zu)%s\n", inf, n, m_,
+                                 inf > 1e-10 ? "\n[ORTHO][WARN] Orthogonality drift above tolerance." : "");
+            }
+        }
     }
-
     void reset_perm() { for (std::size_t i = 0; i < nc_; ++i) perm_[i] = (int)i; perm_dirty_ = false; }
     // apply the deferred swaps to V1 and V2 (distMultiVector.hpp:1493 swap_ij acts on both, pchase_cpu.hpp Swap)
     void flush_swaps()
@@ -1029,6 +1054,7 @@ protected:
     T* dChk_ = nullptr; std::size_t chk_cols_ = 0, resd_rechecked_ = 0;   // scratch of recheck_borderline
     long forced_recheck_ = -1;                                            // set_forced_recheck (single-rank replay)
     int forced_qr_ = -1; std::size_t forced_qr_retries_ = 0;              // set_forced_qr (single-rank replay)
+    double last_ortho_ = -1.0;                                            // CHASE_QR_CHECK_ORTHO
     R norm_h_ = 0;                                                        // Lanczos upper bound of the last solve (recheck window)
     bool loopback_ = false; std::size_t stage_rows_ = 0;
     T *dV1_ = nullptr, *dV2_ = nullptr, *dVt_ = nullptr, *dW1_ = nullptr, *dW2_ = nullptr, *dA_ = nullptr;

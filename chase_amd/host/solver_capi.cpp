@@ -229,6 +229,7 @@ int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* out)
         else if (name == "clusteraware") *out = c.UseClusterAwareDegrees();
         else if (name == "upperbscale") *out = c.GetUpperbScaleRate();
         else if (name == "locked") *out = (double)s->ex->locked();
+        else if (name == "qr_ortho_check" && (s->pd || s->pz)) *out = s->pz ? s->pz->last_ortho_check() : s->pd->last_ortho_check();
         else if (name == "panel_cols" && (s->pd || s->pz)) *out = (double)(s->pz ? s->pz->panel_cols() : s->pd->panel_cols());
         else if (name == "panel_rounds" && (s->pd || s->pz)) *out = (double)(s->pz ? s->pz->panel_rounds() : s->pd->panel_rounds());
         else if (name == "qr_variant") *out = (double)s->ex->last_qr_variant();

@@ -12,8 +12,9 @@ cd $REPO
 python3 bench.py --replay-rank $GRIDS --workload $WL --tape $TAPE --oplog-out ${OUT}_oplog_%g.txt > ${OUT}_replay.json 2> ${OUT}_replay.log || { tail -20 ${OUT}_replay.log; exit 1; }
 tail -4 ${OUT}_replay.log
 cd /tmp && export TMPDIR=/tmp
+for PROF_GRID in ${PROF_GRIDS:-4x2 2x2 2x1}; do
 rm -rf /tmp/prof_replay
-CHASE_HIP_ROCTX=1 rocprofv3 --kernel-trace --marker-trace --stats -f csv -d /tmp/prof_replay -o replay -- python3 $REPO/bench.py --replay-rank ${PROF_GRID:-4x2} --workload $WL --tape $TAPE > ${OUT}_replay_prof.json 2> ${OUT}_replay_prof.log || { tail -20 ${OUT}_replay_prof.log; exit 1; }
+CHASE_HIP_ROCTX=1 rocprofv3 --kernel-trace --marker-trace --stats -f csv -d /tmp/prof_replay -o replay -- python3 $REPO/bench.py --replay-rank ${PROF_GRID:-4x2} --workload $WL --tape $TAPE > ${OUT}_replay_prof_${PROF_GRID}.json 2> ${OUT}_replay_prof_${PROF_GRID}.log || { tail -20 ${OUT}_replay_prof_${PROF_GRID}.log; exit 1; }
 f=$(find /tmp/prof_replay -name "*kernel_stats.csv" | head -1)
 python3 - "$f" "${PROF_GRID:-4x2}" "$WL" > ${OUT}_replay_${PROF_GRID:-4x2}_kernel_stats.txt <<'PY'
 import csv, sys
@@ -29,4 +30,5 @@ ls -la /tmp/prof_replay/* > ${OUT}_replay_prof_files.txt 2>&1
 head -3 "$kt" > ${OUT}_kernel_trace_head.txt 2>/dev/null
 head -5 "$mt" > ${OUT}_marker_trace_head.txt 2>/dev/null
 python3 $REPO/scripts/phase_table.py "$kt" "$mt" > ${OUT}_replay_${PROF_GRID:-4x2}_phase_table.txt 2>&1 || true
-head -14 ${OUT}_replay_${PROF_GRID:-4x2}_kernel_stats.txt
+head -8 ${OUT}_replay_${PROF_GRID:-4x2}_kernel_stats.txt
+done

@@ -423,6 +423,8 @@ def scenario_qr_fixtures(ctx, grid, comm, cplx, mb=0):
         s.upload_local_V(V[rows, :]); s.initVecs(False)
         s.QR(0, cond)
         variant = int(s.get("qr_variant"))
+        if variant == 0 and os.environ.get("CHASE_QR_CHECK_ORTHO") == "1":
+            assert 0.0 <= s.get("qr_ortho_check") <= 60 * n * EPS, s.get("qr_ortho_check")    # inf-norm of Q^H Q - I over n columns
         objs = comm.all_gather_object((grid.myrow, grid.mycol, s.local_V()))
         Q = np.zeros_like(V)
         for (i, j, blk) in objs:
@@ -453,11 +455,13 @@ def scenario_qr_fixtures(ctx, grid, comm, cplx, mb=0):
     for nb in ("8", "40"):
         comm.barrier()
         os.environ["CHASE_HOUSEHOLDER_NB"] = nb
+        os.environ["CHASE_QR_CHECK_ORTHO"] = "1"     # the reference's diagnostic (nccl/householder_qr.hpp:214-221,292-372)
         comm.barrier()
         v, o = run("cond_1e4.bin", 1e4, cholqr=0); assert v == 0 and o <= 25 * EPS
         v, o = run("cond_ill.bin", 10.0);          assert v == 0 and o <= 25 * EPS
         comm.barrier()
     os.environ.pop("CHASE_HOUSEHOLDER_NB", None)
+    os.environ.pop("CHASE_QR_CHECK_ORTHO", None)
     comm.barrier()
 
 

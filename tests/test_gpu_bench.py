@@ -87,6 +87,14 @@ def test_multi_rank_bench_with_real_rccl_collectives(ngpus, grid):
     assert d["transport_proof"]["col_group"]["ranks"] == 2 and d["transport_proof"]["col_group"]["busbw_GBps"] > 0
     assert d["comm_waits"] > 0 and d["comm_exposed_ms"] > 0                      # the compute stream really waited on collectives
     assert d["comm_probe"]["col_group_panel_allreduce"]["ranks"] == 2
+    # first contact with the "hardware": the panel-pipeline knobs were measured on identical full-width filter steps before
+    # the first solve and the best setting locked (chase_amd/autotune.py); the table is in the line
+    a = d["autotune"]
+    assert a["base"] == {"panel_cols": a["base"]["panel_cols"], "panel_rounds": 4, "comm_streams": 2}
+    assert 2 <= len(a["trials"]) <= 5 and a["trials"][0]["setting"] == a["base"]
+    assert sum(t["kept"] for t in a["trials"]) == 1 and [t for t in a["trials"] if t["kept"]][0]["setting"] == a["chosen"]
+    assert all(t["seconds"] > 0 for t in a["trials"])
+    assert d["scaling_valid"] is True
 
 
 def test_config3_at_full_size_over_real_rccl_communicators():
@@ -95,7 +103,8 @@ def test_config3_at_full_size_over_real_rccl_communicators():
     transport (one NCCL_HOSTID per rank): same iteration and filtered-vector counts as the host-fabric run of
     tests/test_gpu_fullsize.py, analytic spectrum, independent residuals."""
     d = run_bench("--gpus", "4", "--workload", "cfg3", "--steps", "9", "--warmup", "0", "--no-cpu-baseline", "--no-probe",
-                  env={"CHASE_BENCH_FAKE_HOSTS": "1"})
+                  "--no-autotune", env={"CHASE_BENCH_FAKE_HOSTS": "1"})
+    assert d["autotune"] is None
     assert d["n_gpus"] == 4 and d["config"]["grid"] == "2x2" and d["config"]["transport"] == "rccl" and d["dtype"] == "f64"
     assert d["ranks_seen_by_rccl"]["grid"] == 4
     assert d["iterations_per_solve"] == 9 and abs(d["filtered_vecs_per_solve"] - 207784) <= 0.005 * 207784
