@@ -446,7 +446,7 @@ def run_single(args):
     spec = spectrum_check(lam, N, nev)
     # independent check outside the timed region (the reference's solve tests: tests/chase_serial_solve.cpp:144-148,195-199):
     # one fresh four-product H V over the nev eigenvectors of the last solve + the residual-norm kernel.  The solver's own
-    # residuals come from (H Q) A left behind by Rayleigh-Ritz (DESIGN.md 3.1b), these from H itself.
+    # residuals come from (H Q) A left behind by Rayleigh-Ritz (DESIGN.md 3), these from H itself.
     resid_re = s.recompute_residuals(nev, lam)
     ok = converged_ok(lam, resid, resid_re, s.get("tol"), spec)
     st = complete[-1]

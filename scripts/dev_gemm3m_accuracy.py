@@ -1,4 +1,4 @@
-"""development: accuracy of the 3M filter kernel vs the 4M kernel against a long-double reference."""
+"""development: accuracy of the 3M filter kernel vs the 4M kernel against a long-double reference (HISTORY.md §3.1c)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 """development: the same operator sequence on the sequential Impl and on the grid Impl (1 x 1 grid), compared after every step - how the
-LanczosDos / V2 difference of the two reference Impls was found"""
+LanczosDos / V2 difference of the two reference Impls was found (HISTORY.md section 5)"""
 import os, sys, ctypes as C
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -441,7 +441,7 @@ def _ld_matmul(A, B):
 
 @pytest.mark.parametrize("imag_scale", [1.0, 1e-8])
 def test_three_vs_four_multiplication_accuracy(ctx, imag_scale):
-    """The filter's three-multiplication complex scheme against a long-double product, next to the
+    """The filter's three-multiplication complex scheme (HISTORY.md §3.1c) against a long-double product, next to the
     four-multiplication kernel (the reference's zgemm arithmetic), on generic AND on nearly real operands (the bench matrix
     is nearly real): 3M must meet the NORMWISE bound |C - AB| <= c k eps |A||B| (entrywise in terms of the moduli), 4M the
     componentwise-in-real-arithmetic bound on the real and on the imaginary part separately.  Also checks the switch: the
