@@ -332,6 +332,7 @@ _sig("chase_hip_op_lanczos", c_int, c_void_p, c_size_t, c_size_t, P(c_double), c
 _sig("chase_hip_op_lanczos_dos", c_int, c_void_p, c_size_t, c_size_t, c_void_p)
 _sig("chase_hip_op_check_symmetry", c_int, c_void_p, P(c_int))
 _sig("chase_hip_op_sym_or_herm", c_int, c_void_p, c_char)
+_sig("chase_hip_complete_hermitian", c_int, c_void_p, c_int, c_char, c_int, c_void_p, c_long)
 _sig("chase_hip_hash64", c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_long, P(C.c_ulonglong))
 _sig("chase_hip_cols_indexed", c_int, c_void_p, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_int)
 _sig("chase_hip_tri_mask_bc", c_int, c_void_p, c_int, c_char, c_int, c_int, c_void_p, c_long, c_long, c_int, c_int, c_long, c_int,

@@ -176,6 +176,23 @@ int chase_hip_cols_indexed(chase_hip_ctx* c, int cplx, int m, const void* in, lo
     return 0;
 }
 
+/* A (n x n, device) <- Hermitian completion of its stored triangle: uplo 'U': A[i,j] = conj(A[j,i]) for i > j, 'L' the other
+ * way round; the diagonal is left as it is - cpu::symOrHermMatrix (linalg/internal/cpu/symOrHerm.hpp:111-134) on a matrix that
+ * lives in HBM */
+int chase_hip_complete_hermitian(chase_hip_ctx* c, int cplx, char uplo, int n, void* A, long lda)
+{
+    if (!c) return set_error(CHASE_HIP_EINVAL, "complete_hermitian: NULL ctx");
+    (void)hipSetDevice(c->device);      // entry points may be called with another device current
+    if (c->oplog_on) c->oplog_add("complete_hermitian", n, uplo, 0, 0);
+    if (uplo != 'U' && uplo != 'L' && uplo != 'u' && uplo != 'l') return set_error(CHASE_HIP_EINVAL, "complete_hermitian: uplo must be 'U' or 'L'");
+    if (n < 0 || lda < n) return set_error(CHASE_HIP_EINVAL, "complete_hermitian: bad shape");
+    if (n == 0) return 0;
+    if (!A) return set_error(CHASE_HIP_EINVAL, "complete_hermitian: NULL matrix");
+    if (uplo == 'U' || uplo == 'u') KCHK(mirror_upper(c->stream, (double*)A, lda, n, ept_of(cplx)), "mirror_upper");
+    else KCHK(mirror_lower(c->stream, (double*)A, lda, n, ept_of(cplx), 0), "mirror_lower");
+    return 0;
+}
+
 /* Triangle mask of a block-cyclic shard: entries of the triangle that is not kept (uplo 'U': the strictly lower one, 'L': the
  * strictly upper one, by GLOBAL position) become 0, diagonal entries are halved - the first step of the distributed
  * symOrHermMatrix (linalg/internal/mpi/symOrHerm.hpp:138-170,232-296) */

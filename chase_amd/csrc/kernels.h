@@ -59,7 +59,7 @@ int conj_inplace(hipStream_t st, double* X, long ldx_d, int m, int ncols);
 int pack_upper(hipStream_t st, const double* A, long lda, int n, int ept, double* P);
 int unpack_upper(hipStream_t st, double* P, int n, int ept, double* A, long lda);
 int mirror_upper(hipStream_t st, double* A, long lda, int n, int ept);
-int mirror_lower(hipStream_t st, double* A, long lda, int n, int ept);
+int mirror_lower(hipStream_t st, double* A, long lda, int n, int ept, int zero_diag_imag = 1);
 
 // ---- generators (gen_kernels.hip) ----
 int fill_normal(hipStream_t st, bool cplx, double* X, long ldx, int m, int n, long grow0, long gcol0, long gld,

@@ -422,10 +422,10 @@ __global__ __launch_bounds__(256) void hash64_kernel(const unsigned long long* _
 }
 
 // A[i,j] = conj(A[j,i]) for i < j (rebuild the strictly-upper triangle from the lower one) and Im A[j,j] = 0
-__global__ void mirror_lower_kernel(double* __restrict__ A, long lda, int n, int ept)
+__global__ void mirror_lower_kernel(double* __restrict__ A, long lda, int n, int ept, int zero_diag_imag)
 {
     const int j = blockIdx.x;                                   // column of the lower triangle being read
-    if (threadIdx.x == 0 && ept == 2) A[((long)j * lda + j) * 2 + 1] = 0.0;
+    if (threadIdx.x == 0 && ept == 2 && zero_diag_imag) A[((long)j * lda + j) * 2 + 1] = 0.0;
     for (int i = j + 1 + threadIdx.x; i < n; i += blockDim.x) {
         const double* s = A + ((long)j * lda + i) * ept;        // A[i,j] (lower)
         double* d = A + ((long)i * lda + j) * ept;              // A[j,i] (upper)
@@ -597,10 +597,10 @@ int unpack_upper(hipStream_t st, double* P, int n, int ept, double* A, long lda)
     hipLaunchKernelGGL(pack_upper_kernel, dim3(n), dim3(128), 0, st, (const double*)nullptr, lda, n, ept, P, 1, A);
     return (int)hipGetLastError();
 }
-int mirror_lower(hipStream_t st, double* A, long lda, int n, int ept)
+int mirror_lower(hipStream_t st, double* A, long lda, int n, int ept, int zero_diag_imag)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(mirror_lower_kernel, dim3(n), dim3(128), 0, st, A, lda, n, ept);
+    hipLaunchKernelGGL(mirror_lower_kernel, dim3(n), dim3(128), 0, st, A, lda, n, ept, zero_diag_imag);
     return (int)hipGetLastError();
 }
 int mirror_upper(hipStream_t st, double* A, long lda, int n, int ept)

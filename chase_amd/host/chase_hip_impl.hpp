@@ -121,7 +121,11 @@ public:
     // complete the other triangle from `uplo` on the caller's host copy (reference: cpu::symOrHermMatrix)
     void symOrHermMatrix(char uplo) override
     {
-        if (h_on_device_) throw std::logic_error("symOrHermMatrix: H is device resident");
+        if (h_on_device_) {             // the caller's matrix lives in HBM: completed in place there (round 5)
+            hip_ok(chase_hip_complete_hermitian(ctx_, CP, uplo, (int)N_, dH_, (long)ldd_h_), "complete_hermitian");
+            hv_valid_ = false;
+            return;
+        }
         const bool up = (uplo == 'U' || uplo == 'u');
         for (std::size_t j = 0; j < N_; ++j)
             for (std::size_t i = 0; i < j; ++i) {

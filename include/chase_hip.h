@@ -127,6 +127,9 @@ int chase_hip_hash64(chase_hip_ctx* ctx, int cplx, int m, int n, const void* A, 
 /* column gather by a device index list: out[:, c] = in[:, idx[c]], c < ncols */
 int chase_hip_cols_indexed(chase_hip_ctx* ctx, int cplx, int m, const void* in, long ld_in, void* out, long ld_out,
                            const int* idx_dev, int ncols);
+/* Hermitian completion of a device matrix from its stored triangle ('U': lower <- conj(upper)^T, 'L': the other way round; the
+ * diagonal is left alone) - cpu::symOrHermMatrix (linalg/internal/cpu/symOrHerm.hpp:111-134) for a matrix that lives in HBM */
+int chase_hip_complete_hermitian(chase_hip_ctx* ctx, int cplx, char uplo, int n, void* A, long lda);
 /* the two local steps of the distributed symOrHermMatrix (linalg/internal/mpi/symOrHerm.hpp:127-320): the triangle mask of a
  * block-cyclic shard by global position (kept triangle untouched, the other one zeroed, diagonal halved), and
  * H[colmap[b], rowmap[a]] += conj(P[a, b]) - the conjugate transpose of a received piece added into the shard */

@@ -193,6 +193,39 @@ def test_check_symmetry(ctx):
 
 
 @pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("uplo", ["U", "L"])
+def test_sym_or_herm_matrix_host_and_device_resident(ctx, cplx, uplo):
+    """symOrHermMatrix(uplo) of the sequential Impl (linalg/internal/cpu/symOrHerm.hpp:111-134; the reference's unit test
+    tests/linalg/internal/cpu/symOrHerm.cpp: a triangular matrix is not symmetric, after the call it is): on the caller's host
+    matrix, and - round 5 - in place in HBM when the matrix was handed over on the device.  Entry by entry: the other triangle
+    is the conjugate transpose of the stored one, the diagonal is untouched."""
+    from chase_amd.capi import Solver
+    rng = np.random.default_rng(3)
+    N = 203
+    A = rng.standard_normal((N, N)) + (1j * rng.standard_normal((N, N)) if cplx else 0)
+    A = np.asfortranarray(A)
+    keep = np.triu(A, 1) if uplo == "U" else np.tril(A, -1)
+    want = keep + keep.conj().T + np.diag(np.diag(A))
+    # host-resident
+    H = np.array(np.triu(A) if uplo == "U" else np.tril(A), order="F")
+    s = Solver(ctx, H, 8, 8)
+    assert not s.checkSymmetryEasy()
+    s.symOrHermMatrix(uplo)
+    assert np.array_equal(H, want)
+    if not cplx or np.all(np.diag(A).imag == 0):
+        assert s.checkSymmetryEasy()
+    s.close()
+    # device-resident
+    dH = ctx.array(np.array(np.triu(A) if uplo == "U" else np.tril(A), order="F"))
+    s = Solver(ctx, None, 8, 8, h_on_device_ptr=dH.ptr, N=N, cplx=cplx)
+    assert not s.checkSymmetryEasy()
+    s.symOrHermMatrix(uplo.lower())
+    assert np.array_equal(dH.download(), want)
+    s.close()
+    dH.free()
+
+
+@pytest.mark.parametrize("cplx", [False, True])
 def test_c_interface_shim(ctx, cplx):
     """dchase_init_/dchase_/dchase_finalize_ (interface/chase_c_interface.h:13-41), incl. the approximate-restart mode of
     the sequence examples (docs/example/sequence.rst): a second solve started from the previous eigenvectors."""
