@@ -7,9 +7,11 @@ Restates, on numpy blocks + gloo collectives (file:line relative to /root/refere
   rayleighRitz                                                                      linalg/internal/mpi/rayleighRitz.hpp:103-186
   residuals                                                                         linalg/internal/mpi/residuals.hpp:61-107
   column-type -> row-type redistribution                                            linalg/distMatrix/distMultiVector.hpp:2585-2720
-using the product's layout helpers (chase_hip_block_len / numroc / owner / local_index — pure host arithmetic restating
-linalg/distMatrix/distMatrix.hpp:44-67,1992-2052), so the world_size-2/4 gloo tests pin exactly the index maps and the
-group structure (row group = reference row_comm, column group = col_comm, column-major grid) the HIP path uses.
+with its OWN index arithmetic (round 5; rounds 2-4 borrowed the product's chase_amd.dist.Layout, so a layout bug would have
+been shared): OLayout below restates the block rule and numroc (linalg/distMatrix/distMatrix.hpp:44-67,1992-2052), the grid
+coordinates and communicators are the reference's column-major MpiGrid2D (grid/mpiGrid2D.hpp:402-446: row_comm = ranks of
+one grid row, col_comm = ranks of one grid column).  tests/test_dist_cpu.py then compares these index maps with the
+product's layout helpers instead of sharing them.
 Pinned by the reference's distributed HEMM known answer (tests/linalg/internal/mpi/hemm.cpp:36-119) and by agreement with
 the serial oracle, which is itself pinned in tests/test_oracle_pins.py."""
 import numpy as np
@@ -17,18 +19,71 @@ import scipy.linalg as sla
 import torch
 import torch.distributed as dist
 
-from chase_amd import dist as cd
+
+
+class OLayout:
+    """1D block-cyclic map of N indices over p ranks, block size nb (0: the reference's BLOCK layout, whose block length is
+    N / p when that divides and N / p + 1 otherwise, the last rank taking the remainder - distMatrix.hpp:2000-2039)."""
+
+    def __init__(self, N, nb, p):
+        self.N, self.p = int(N), int(p)
+        if nb:
+            self.nb = int(nb)
+        else:
+            self.nb = self.N // self.p if self.N % self.p == 0 else min(self.N // self.p + 1, self.N)
+
+    def count(self, q):
+        """ScaLAPACK NUMROC with source process 0 (distMatrix.hpp:44-67)"""
+        nblocks = self.N // self.nb
+        n = (nblocks // self.p) * self.nb
+        extra = nblocks % self.p
+        if q < extra:
+            n += self.nb
+        elif q == extra:
+            n += self.N % self.nb
+        return n
+
+    def owner(self, g):
+        return (int(g) // self.nb) % self.p
+
+    def local(self, g):
+        g = int(g)
+        return (g // (self.nb * self.p)) * self.nb + g % self.nb
+
+    def globals_of(self, q):
+        return np.array([g for g in range(self.N) if self.owner(g) == q], dtype=np.int64)
+
+
+def grid_coords(rank, nprow):
+    """column-major grid ordering (grid/mpiGrid2D.hpp:402-432): rank = row + col * nprow"""
+    return rank % nprow, rank // nprow
+
+
+def make_groups(nprow, npcol):
+    """row_comm / col_comm of every rank (grid/mpiGrid2D.hpp:433-446); all ranks create all groups in the same order"""
+    rank = dist.get_rank()
+    myrow, mycol = grid_coords(rank, nprow)
+    out = {}
+    for i in range(nprow):
+        g = dist.new_group([i + j * nprow for j in range(npcol)])
+        if i == myrow:
+            out["row"] = g
+    for j in range(npcol):
+        g = dist.new_group([i + j * nprow for i in range(nprow)])
+        if j == mycol:
+            out["col"] = g
+    return out
 
 
 class DistBlocks:
     def __init__(self, N, nprow, npcol, mb=0, nb=0):
         self.rank = dist.get_rank()
         self.nprow, self.npcol = nprow, npcol
-        self.myrow, self.mycol = cd.coords_of(self.rank, nprow)
-        self.rl, self.cl = cd.Layout(N, mb, nprow), cd.Layout(N, nb, npcol)
+        self.myrow, self.mycol = grid_coords(self.rank, nprow)
+        self.rl, self.cl = OLayout(N, mb, nprow), OLayout(N, nb, npcol)
         self.rows = self.rl.globals_of(self.myrow)            # global rows of column-type blocks / of H_loc
         self.cols = self.cl.globals_of(self.mycol)            # global rows of row-type blocks / columns of H_loc
-        self.pg = cd.make_process_groups(nprow, npcol)
+        self.pg = make_groups(nprow, npcol)
         self.N = N
 
     def allreduce(self, a, group):

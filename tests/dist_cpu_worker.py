@@ -46,7 +46,19 @@ def main():
     r = D.residuals(Hl, Vr, w)
     r0 = O.residuals(H, w0, V0)
     assert np.allclose(r, r0, atol=1e-8 * max(1.0, r0.max()))
-    # 3) layout helpers: every global index is owned exactly once and round-trips
+    # 3) the oracle's OWN index arithmetic (oracle/dist_oracle.py OLayout, restating distMatrix.hpp:44-67,1992-2052) and the
+    #    PRODUCT's layout helpers (chase_hip_numroc / owner / local_index through chase_amd.dist.Layout) are two independent
+    #    implementations of the reference's rule: they must agree index for index
+    for (olay, p, nbsz) in ((D.rl, nprow, mb), (D.cl, npcol, mb)):
+        play = cd.Layout(N, nbsz, p)
+        assert play.nb == olay.nb
+        for q in range(p):
+            assert play.count(q) == olay.count(q)
+            assert np.array_equal(play.globals_of(q), olay.globals_of(q))
+        for g in range(N):
+            assert play.owner(g) == olay.owner(g) and play.local(g) == olay.local(g)
+    assert cd.coords_of(rank, nprow) == (D.myrow, D.mycol)
+    # every global index is owned exactly once and round-trips
     for lay, p in ((D.rl, nprow), (D.cl, npcol)):
         seen = np.zeros(N, dtype=int)
         for q in range(p):

@@ -1,5 +1,6 @@
-"""world_size-2 / -4 gloo tests on CPU: the distributed oracle (reference pChASECPU kernels restated on gloo) built on
-the product's layout helpers agrees with the serial oracle and with the reference's distributed HEMM known answer."""
+"""world_size-2 / -4 gloo tests on CPU: the distributed oracle (reference pChASECPU kernels restated on gloo, with its OWN
+layout arithmetic) agrees with the serial oracle, with the reference's distributed HEMM known answer, and - index for index -
+with the product's layout helpers."""
 import os
 import subprocess
 import sys
@@ -56,3 +57,23 @@ def test_grid_coordinates_and_shard_shapes_reference_known_answers():
             assert all(lay.owner(int(x)) == q for x in g[:50]) and all(lay.local(int(x)) == l for l, x in enumerate(g[:50]))
             seen.extend(int(x) for x in g)
         assert sorted(seen) == list(range(N))
+
+
+def test_oracle_layout_is_independent_of_the_product_and_agrees_with_it():
+    """oracle/dist_oracle.py restates the block rule and numroc itself (distMatrix.hpp:44-67,1992-2052); the product computes
+    them in C (chase_hip_block_len / numroc / owner / local_index).  Two implementations, one rule: equal on the reference's
+    known answers and on awkward sizes, zero-row ranks included (N = 9 on 4 ranks: 3, 3, 3, 0)."""
+    from chase_amd import dist as cd
+    from oracle.dist_oracle import OLayout, grid_coords
+    import inspect
+    import oracle.dist_oracle as D
+    assert "chase_amd" not in inspect.getsource(D).split('"""', 2)[2]        # (outside its doc string: no import of the product)
+    for (N, nb, p) in [(11, 2, 2), (1001, 64, 4), (10, 0, 4), (9, 0, 4), (65536, 64, 4), (37, 5, 3), (203, 16, 2), (7, 0, 7), (5, 0, 2)]:
+        o, q = OLayout(N, nb, p), cd.Layout(N, nb, p)
+        assert o.nb == q.nb
+        assert [o.count(i) for i in range(p)] == [q.count(i) for i in range(p)]
+        for g in range(0, N, max(1, N // 997)):
+            assert o.owner(g) == q.owner(g) and o.local(g) == q.local(g)
+    assert [OLayout(9, 0, 4).count(i) for i in range(4)] == [3, 3, 3, 0]
+    assert [OLayout(11, 2, 2).count(i) for i in range(2)] == [6, 5]              # tests/matrix/distMatrix.cpp:343-389
+    assert [grid_coords(r, 2) for r in range(4)] == [(0, 0), (1, 0), (0, 1), (1, 1)]   # tests/grid/mpiGrid2D.cpp:80-132
