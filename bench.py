@@ -747,6 +747,9 @@ def main():
     ap.add_argument("--replay-panel", type=int, default=0, help="replay: panel width of the pipelined HEMM (columns)")
     ap.add_argument("--replay-panel-rounds", type=int, default=-1, help="replay: K-piece granularity of the panel products (0 = off)")
     ap.add_argument("--replay-comm-streams", type=int, default=0, help="replay: 1 or 2 communication streams")
+    ap.add_argument("--replay-autotune", type=int, default=0, metavar="TRIALS",
+                    help="replay: run the first-contact self-tuning (chase_amd/autotune.py) on the replayed rank first, with this "
+                         "trial budget, against the modelled collectives")
     ap.add_argument("--replay-no-pipeline", action="store_true", help="replay: every collective waited for where it is issued")
     ap.add_argument("--tape", default=None, help="scalar tape file (.npz): loaded if it exists, else recorded and saved there")
     ap.add_argument("--replay-rank-index", type=int, default=0, help="which rank of the grid is replayed (default 0 = (0,0))")

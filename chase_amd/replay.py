@@ -86,6 +86,20 @@ def replay_rank(ctx, tape, meta, nprow, npcol, rank=0, block_cyclic=None, oplog=
         s.set(panel_cols=settings["panel_cols"])
     if settings and settings.get("panel_rounds") is not None:
         s.set(panel_rounds=settings["panel_rounds"])
+    tuned = None
+    if settings and settings.get("autotune"):
+        # the first-contact self-tuning of the multi-GPU bench (chase_amd/autotune.py) on this lone rank: its trial steps run
+        # against the MODELLED collectives, which exercises the whole mechanism (in-process setters, identical trial steps,
+        # selection) on one GPU; on the real node the same code runs on every rank with max-over-ranks timings
+        from .autotune import first_contact
+
+        class _Solo:
+            rank, world = 0, 1
+            def barrier(self): pass
+            def allreduce_max(self, v): return [float(x) for x in v]
+
+        tuned = first_contact(s, ctx, grid, _Solo(), nev + nex, budget=int(settings["autotune"]), log=log)
+        s.set(reset_counters=1)
     tape_load(s, tape)
     tape_mode(s, 2)
     per_iter = []
@@ -139,7 +153,7 @@ def replay_rank(ctx, tape, meta, nprow, npcol, rank=0, block_cyclic=None, oplog=
                            "%.0f GB/s bus bandwidth%s"
                            % (model.get("workgroups", 0) or 32, model.get("latency_us", 0.0), model.get("busbw_GBps", 0.0),
                               ", plus one read+write pass over the payload" if model.get("touch") else "")),
-           "loopback_model": model, "settings": {k: v for k, v in (settings or {}).items() if k != "loopback_model"}}
+           "autotune": tuned, "loopback_model": model, "settings": {k: v for k, v in (settings or {}).items() if k != "loopback_model"}}
     if lines is not None:
         rec["oplog_lines"] = len(lines)
     s.close()
@@ -193,6 +207,8 @@ def run(args):
         base_settings["pipeline"] = 0
     if args.replay_panel_rounds >= 0:
         base_settings["panel_rounds"] = args.replay_panel_rounds
+    if args.replay_autotune:
+        base_settings["autotune"] = args.replay_autotune
     for spec, model in [(g, m) for g in args.replay_rank.split(",") for m in variants]:
         r, c = (int(x) for x in spec.lower().split("x"))
         rec, lines = replay_rank(ctx, tape, meta, r, c, rank=args.replay_rank_index, oplog=bool(args.oplog_out), log=log,

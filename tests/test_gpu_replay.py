@@ -126,7 +126,17 @@ def test_replay_through_bench_cli(tmp_path):
         assert r["local_shape_H"] == [2048, 4096 // int(r["grid"][-1])]
         assert r["T_rank_seconds"] > 0 and r["waits_on_communication_streams"] > 0
         assert os.path.getsize(tmp_path / f"oplog_{r['grid']}.txt") > 1000
-    # a second call loads the tape instead of solving again
-    p = subprocess.run(cmd[:-2] + ["--replay-rank-index", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    # a second call loads the tape instead of solving again; another rank of the grids, against MODELLED collectives (each holds
+    # its communication stream and 8 RCCL-sized workgroups for 20 us + wire bytes / 20 GB/s), after the first-contact self-tuning
+    # of the panel pipeline has run on the replayed rank (three trials)
+    p = subprocess.run(cmd[:-2] + ["--replay-rank-index", "1", "--loopback-busbw", "20", "--loopback-wgs", "8", "--replay-autotune", "3"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     assert "tape loaded" in p.stderr
+    out2 = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    for r, r0 in zip(out2["replays"], out["replays"]):
+        assert r["rank"] == 1 and r["call_sequence_equals_recording"] and r["qr_variant_mismatches"] == 0
+        assert r["loopback_model"] == {"busbw_GBps": 20.0, "latency_us": 20.0, "touch": True, "workgroups": 8}
+        assert r["exposed_ms_of_those_waits_with_nothing_on_the_wire"] > r0["exposed_ms_of_those_waits_with_nothing_on_the_wire"]
+        a = r["autotune"]
+        assert len(a["trials"]) == 3 and sum(t["kept"] for t in a["trials"]) == 1 and a["chosen"]["comm_streams"] == 2
