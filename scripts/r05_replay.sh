@@ -7,10 +7,13 @@ OUT=$REPO/gpurun_out/$TAG
 GRIDS=${GRIDS:-4x2,2x2,2x1}
 WL=${WL:-cfg4}
 TAPE=${TAPE:-$REPO/gpurun_out/${TAG}_${WL}_tape.npz}
+case $TAPE in /*) ;; *) TAPE=$REPO/$TAPE ;; esac          # (the profiled runs start from /tmp)
 mkdir -p $REPO/gpurun_out
 cd $REPO
+if [ "${SKIP_MAIN:-0}" != "1" ]; then
 python3 bench.py --replay-rank $GRIDS --workload $WL --tape $TAPE --oplog-out ${OUT}_oplog_%g.txt > ${OUT}_replay.json 2> ${OUT}_replay.log || { tail -20 ${OUT}_replay.log; exit 1; }
 tail -4 ${OUT}_replay.log
+fi
 cd /tmp && export TMPDIR=/tmp
 for PROF_GRID in ${PROF_GRIDS:-4x2 2x2 2x1}; do
 rm -rf /tmp/prof_replay
