@@ -30,11 +30,14 @@ struct chase_hip_grid {
     int lb_wgs = 32;                                  // workgroups of the stand-in kernel (RCCL: one per channel)
     bool force = false;                               // CHASE_HIP_RCCL_FORCE: run size-1 groups through RCCL too (testing)
     ncclComm_t comm[2] = {nullptr, nullptr};          // [ROW], [COL]
-    // one communication stream per group: on a 4 x 2 grid the row and column communicators use disjoint xGMI links, so
-    // their collectives need not queue behind each other (CHASE_HIP_COMM_STREAMS=1 / chase_hip_grid_set_comm_streams
-    // put both groups on stream 0 - round 4's behaviour)
+    // Communication streams: ONE for both groups by default; optionally one per group (CHASE_HIP_COMM_STREAMS=2 /
+    // chase_hip_grid_set_comm_streams(2)): on a 4 x 2 grid the row and column communicators use disjoint xGMI links, so
+    // their collectives need not queue behind each other.  Why not the default: measured over RCCL's socket transport
+    // (profiles/r05_socket_rccl_streams.txt), collectives that alternate between two communicators on two streams cost
+    // ~19 ms each instead of ~1 ms on one stream (this RCCL orders the launches of a process's communicators host-side) -
+    // nobody has seen what xGMI does, so two streams are a candidate the first-contact self-tuning measures, not a bet.
     hipStream_t comm_stream[2] = {nullptr, nullptr};
-    int nstreams = 2;
+    int nstreams = 1;
     bool pending[2] = {false, false};                 // collectives issued on stream i since the compute stream last waited
     hipEvent_t ev_compute = nullptr, ev_comm[2] = {nullptr, nullptr};
     hipStream_t stream_of(int group) const { return comm_stream[nstreams == 2 ? group : 0]; }

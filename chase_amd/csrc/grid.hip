@@ -78,7 +78,7 @@ static int grid_common(chase_hip_grid* g, chase_hip_ctx* ctx, int nprow, int npc
         HIPCHK(hipEventCreateWithFlags(&g->ev_comm[i], hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&g->ev_compute, hipEventDisableTiming));
-    if (const char* e = getenv("CHASE_HIP_COMM_STREAMS")) g->nstreams = atoi(e) == 1 ? 1 : 2;
+    if (const char* e = getenv("CHASE_HIP_COMM_STREAMS")) g->nstreams = atoi(e) == 2 ? 2 : 1;
     HIPCHK(hipMalloc((void**)&g->scal_dev, 64));
     return 0;
 }
@@ -158,9 +158,13 @@ int chase_hip_grid_create_rccl(chase_hip_grid** out, chase_hip_ctx* ctx, int npr
         // first collective on a communicator sets up the xGMI connections (hundreds of ms): pay it here, not in the first
         // filter step, and surface transport problems at construction
         HIPCHK(hipMemsetAsync(g->scal_dev, 0, 64, g->comm_stream[0]));
-        for (int grp = 0; grp < 2; ++grp)
-            if (g->comm[grp]) NCCLCHK(ncclAllReduce(g->scal_dev, g->scal_dev, 8, ncclDouble, ncclSum, g->comm[grp], g->comm_stream[0]));
         HIPCHK(hipStreamSynchronize(g->comm_stream[0]));
+        // (each communicator on the stream its collectives will use)
+        for (int grp = 0; grp < 2; ++grp)
+            if (g->comm[grp]) {
+                NCCLCHK(ncclAllReduce(g->scal_dev, g->scal_dev, 8, ncclDouble, ncclSum, g->comm[grp], g->stream_of(grp)));
+                HIPCHK(hipStreamSynchronize(g->stream_of(grp)));
+            }
         return 0;
     }();
     if (rc) {
@@ -249,8 +253,8 @@ int chase_hip_grid_destroy(chase_hip_grid* g)
     return 0;
 }
 
-/* 1: both groups' collectives on one communication stream (round 4's behaviour); 2 (default): one stream per group.  Only
- * between collectives: the compute stream first waits for everything issued so far. */
+/* 1 (default): both groups' collectives on one communication stream; 2: one stream per group.  Only between collectives:
+ * everything issued so far is waited for first. */
 int chase_hip_grid_set_comm_streams(chase_hip_grid* g, int n)
 {
     if (!g || (n != 1 && n != 2)) return set_error(CHASE_HIP_EINVAL, "set_comm_streams: 1 or 2");

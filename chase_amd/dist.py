@@ -226,7 +226,7 @@ class Grid:
               "set_loopback_model")
 
     def set_comm_streams(self, n):
-        """1: both groups' collectives on one communication stream, 2: one stream per group (default)."""
+        """1 (default): both groups' collectives on one communication stream, 2: one stream per group."""
         check(lib.chase_hip_grid_set_comm_streams(self.h, int(n)), "set_comm_streams")
 
     def comm_streams(self):

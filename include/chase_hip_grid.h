@@ -62,8 +62,10 @@ int chase_hip_fabric_abort(chase_hip_fabric* f);
 int chase_hip_fabric_destroy(chase_hip_fabric* f);
 int chase_hip_grid_create_shared(chase_hip_grid** out, chase_hip_ctx* ctx, int nprow, int npcol, int rank, chase_hip_fabric* f);
 int chase_hip_grid_destroy(chase_hip_grid* g);
-/* communication streams: 2 (default) = one per group - on a 4 x 2 grid the row and column communicators use disjoint xGMI
- * links, so their collectives do not queue behind each other; 1 = both groups on one stream (CHASE_HIP_COMM_STREAMS=1).
+/* communication streams: 1 (default) = both groups on one stream; 2 = one per group - on a 4 x 2 grid the row and column
+ * communicators use disjoint xGMI links, so their collectives need not queue behind each other (CHASE_HIP_COMM_STREAMS=2).
+ * Not the default because RCCL's socket transport shows a 20x latency penalty for collectives alternating between two
+ * communicators on two streams (profiles/r05_socket_rccl_streams.txt); the multi-GPU bench measures both at first contact.
  * Callable between collectives (it synchronises the communication streams). */
 int chase_hip_grid_set_comm_streams(chase_hip_grid* g, int n);
 int chase_hip_grid_comm_streams(chase_hip_grid* g);

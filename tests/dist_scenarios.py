@@ -292,7 +292,7 @@ def scenario_knob_switching(ctx, grid, comm, N, nev, nex, cplx, mb, deg):
     s = cd.DistSolver(ctx, grid, dH, N, nev, nex, cplx, mb, mb)
     s.set(deg=deg)
     base = A.current_setting(s, grid)
-    assert base["comm_streams"] == 2 and base["panel_rounds"] == 4 and base["panel_cols"] >= 256
+    assert base["comm_streams"] == 1 and base["panel_rounds"] == 4 and base["panel_cols"] >= 256
     st0 = s.solve()
     lam0 = s.ritzv[:nev].copy()
     cycle = [{"panel_cols": 64, "panel_rounds": 0, "comm_streams": 1}, {"panel_cols": 512, "panel_rounds": 4, "comm_streams": 2},
@@ -773,6 +773,35 @@ def scenario_p2p(ctx, grid, comm):
 
 
 
+def scenario_comm_latency(ctx, grid, comm, reps=200):
+    """development: what a small synchronous collective costs, alternating between the column and the row communicator, with one
+    and with two communication streams (and, for reference, the same number of collectives on ONE communicator)"""
+    import time
+    import ctypes as C
+    from chase_amd.capi import lib
+    x = ctx.array(np.ones((64, 1)))
+    big = ctx.array(np.ones((1 << 20, 1)))
+    out = {}
+    for streams in (1, 2, 1, 2):
+        grid.set_comm_streams(streams)
+        for label, seq, buf, cnt in (("alternating_small", (cd.COL, cd.ROW), x, 64), ("col_only_small", (cd.COL, cd.COL), x, 64),
+                                     ("alternating_8MB", (cd.COL, cd.ROW), big, 1 << 20)):
+            for g in seq:
+                lib.chase_hip_grid_allreduce(grid.h, g, C.c_void_p(buf.ptr), cnt, 0)
+            ctx.sync(); comm.barrier()
+            t = time.perf_counter()
+            n = reps if cnt == 64 else 20
+            for _ in range(n):
+                for g in seq:
+                    assert lib.chase_hip_grid_allreduce(grid.h, g, C.c_void_p(buf.ptr), cnt, 0) == 0
+            ctx.sync()
+            dt = (time.perf_counter() - t) / (2 * n) * 1e3
+            out.setdefault(f"{label}_streams{streams}", []).append(round(dt, 3))
+    res = comm.all_gather_object(out)
+    if comm.rank == 0:
+        print("COMM_LATENCY ms per collective:", res[0], flush=True)
+
+
 def run_named(scen, ctx, grid, comm, argv):
     """command-line form of the scenarios (tests/dist_worker.py)"""
     z = lambda a: a == "z"
@@ -790,6 +819,8 @@ def run_named(scen, ctx, grid, comm, argv):
         scenario_qr_fixtures(ctx, grid, comm, z(argv[0]), int(argv[1]) if len(argv) > 1 else 0)
     elif scen == "symcheck":
         scenario_symcheck(ctx, grid, comm, z(argv[0]), int(argv[1]))
+    elif scen == "comm_latency":
+        scenario_comm_latency(ctx, grid, comm)
     elif scen == "sym_or_herm":
         scenario_sym_or_herm(ctx, grid, comm, z(argv[0]), int(argv[1]))
     elif scen == "knobs":

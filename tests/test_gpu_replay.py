@@ -139,4 +139,4 @@ def test_replay_through_bench_cli(tmp_path):
         assert r["loopback_model"] == {"busbw_GBps": 20.0, "latency_us": 20.0, "touch": True, "workgroups": 8}
         assert r["exposed_ms_of_those_waits_with_nothing_on_the_wire"] > r0["exposed_ms_of_those_waits_with_nothing_on_the_wire"]
         a = r["autotune"]
-        assert len(a["trials"]) == 3 and sum(t["kept"] for t in a["trials"]) == 1 and a["chosen"]["comm_streams"] == 2
+        assert len(a["trials"]) == 3 and sum(t["kept"] for t in a["trials"]) == 1 and a["chosen"]["comm_streams"] == 1
