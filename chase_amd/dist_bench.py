@@ -102,6 +102,30 @@ def transport_proof(ctx, grid, comm, nbytes=256 << 20, reps=3):
         rec[name] = {"ranks": size, "ms": ms, "algbw_GBps": nbytes / (ms * 1e-3) / 1e9, "busbw_GBps": busbw}
         if is_rccl and size >= 2 and busbw < MIN_BUSBW_GBPS:
             ok = False
+    # what a SMALL synchronous collective costs (64 doubles: Lanczos scalars, agreement collectives, the residual sums): per
+    # communicator and alternating between the two - over RCCL's socket transport the alternating pattern on two communication
+    # streams costs 20x the single-stream figure (profiles/r05_socket_rccl_streams.txt); reported, never part of `ok`
+    import time
+    small = ctx.empty((64,), np.float64)
+    check(lib.chase_hip_memset(ctx.h, small.ptr, 0, 64 * 8), "memset")
+    groups = [g for g in (COL, ROW) if lib.chase_hip_grid_group_active(grid.h, g)]
+    lat = {}
+    for name, seq in (("col_group", [COL]), ("row_group", [ROW]), ("alternating", [COL, ROW])):
+        if any(g not in groups for g in seq):
+            continue
+        for g in seq:
+            check(lib.chase_hip_grid_allreduce(grid.h, g, small.ptr, 64, 0), "allreduce")
+        ctx.sync()
+        comm.barrier()
+        t = time.perf_counter()
+        n = 50
+        for _ in range(n):
+            for g in seq:
+                check(lib.chase_hip_grid_allreduce(grid.h, g, small.ptr, 64, 0), "allreduce")
+        ctx.sync()
+        lat[name] = comm.allreduce_max([(time.perf_counter() - t) / (n * len(seq)) * 1e6])[0]
+    small.free()
+    rec["small_allreduce_latency_us"] = dict(lat, comm_streams=grid.comm_streams())
     rec["ok"] = ok
     return rec, ok
 
