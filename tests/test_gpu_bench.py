@@ -60,6 +60,8 @@ def test_multi_rank_entry_point_on_one_gpu():
     # every multi-rank run times a 256 MB all-reduce per communicator before it solves (a host-staged RCCL group fails it)
     t = d["transport_proof"]
     assert t["ok"] and t["row_group"]["ranks"] == 2 and t["col_group"]["busbw_GBps"] > 0
+    lat = t["small_allreduce_latency_us"]                       # 64-double all-reduces: per communicator and alternating
+    assert lat["col_group"] > 0 and lat["row_group"] > 0 and lat["alternating"] > 0 and lat["comm_streams"] == 1
 
 
 def test_thread_per_gpu_mode_on_one_gpu():
