@@ -160,7 +160,7 @@ def run_rank(args, comm, ctx, grid, mode):
     # how many ranks RCCL itself counts in this rank's row / column communicator
     print(f"bench rank {rank}/{world} [{mode}]: grid ({myrow},{mycol}) of {nprow}x{npcol}, ordinal {ctx.device}, device bus id "
           f"{ctx.bus_id()}, ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES', '<all>')}, transport "
-          f"{'rccl' if is_rccl else 'host'}, ncclCommCount row {rccl_row} col {rccl_col}", file=sys.stderr, flush=True)
+          f"{'rccl' if is_rccl else grid.transport}, ncclCommCount row {rccl_row} col {rccl_col}", file=sys.stderr, flush=True)
     grid.set_profiling(True)
     # RCCL prints a version banner through C stdio at communicator creation; push it out NOW on every rank so that the
     # JSON line rank 0 prints at the end is the last line of the job's stdout
@@ -256,11 +256,13 @@ def run_rank(args, comm, ctx, grid, mode):
                                    + (("RCCL over xGMI" if os.environ.get("CHASE_BENCH_FAKE_HOSTS") != "1" else
                                        "RCCL over its SOCKET transport between rank processes sharing one GPU (NCCL_HOSTID per rank): "
                                        "a functional rehearsal, not a measurement") if is_rccl
-                                      else "host-callback TEST transport - not a measurement of RCCL")
+                                      else ("shared-device TEST transport (rank threads on ONE GPU, device-side collectives) - not a "
+                                            "measurement of RCCL" if grid.transport == "shared"
+                                            else "host-callback TEST transport - not a measurement of RCCL"))
                                    + f", ranks = {mode}"
                                    + "; step = one outer iteration (filter+QR+RR+residuals+locking), solves back to back",
                        "N": N, "nev": nev, "nex": nex, "grid": f"{nprow}x{npcol}", "step": "outer iteration",
-                       "transport": "rccl" if is_rccl else "host", "ranks": mode},
+                       "transport": "rccl" if is_rccl else grid.transport, "ranks": mode},
             "eigenpairs_per_sec": nev / solve_s, "solve_seconds": solve_s, "complete_solves": len(complete),
             "pct_fp64_mfma_peak": 100.0 * exec_flops / filt_s / 1e12 / world / B.FP64_MFMA_PEAK_TFLOPS,
             "converged": ok, "max_resid": float(np.max(resid)), "max_resid_recomputed": float(np.max(resid_re)),
