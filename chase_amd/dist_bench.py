@@ -280,7 +280,8 @@ def run_rank(args, comm, ctx, grid, mode):
             "ranks_seen_by_rccl": {"row_communicator": rccl_row, "col_communicator": rccl_col,
                                    "grid": rccl_row * rccl_col if is_rccl else None},
             "transport_proof": proof,
-            "scaling_valid": bool(proof_ok and ok),
+            # a scaling number only when RCCL really ran between devices: not on a test transport, not over fake hosts' sockets
+            "scaling_valid": bool(proof_ok and ok and is_rccl and os.environ.get("CHASE_BENCH_FAKE_HOSTS") != "1"),
             "comm_exposed_ms": exposed_ms, "comm_exposed_frac_of_wall": exposed_ms * 1e-3 / wall,
             "comm_waits": int(timer.diff("waits")),
             "roofline": B.roofline_object(model_flops, exec_flops, filt_s, calls, world,

@@ -95,7 +95,7 @@ def test_multi_rank_bench_with_real_rccl_collectives(ngpus, grid):
     assert 2 <= len(a["trials"]) <= 5 and a["trials"][0]["setting"] == a["base"]
     assert sum(t["kept"] for t in a["trials"]) == 1 and [t for t in a["trials"] if t["kept"]][0]["setting"] == a["chosen"]
     assert all(t["seconds"] > 0 for t in a["trials"])
-    assert d["scaling_valid"] is True
+    assert d["scaling_valid"] is False          # RCCL over fake hosts' sockets: a rehearsal, never a scaling number
 
 
 def test_config3_at_full_size_over_real_rccl_communicators():
