@@ -5,7 +5,7 @@
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/${1:-r05s}
 cd $REPO
-for v in "pipeline1_streams2 CHASE_HIP_PIPELINE=1 CHASE_HIP_COMM_STREAMS=2" "pipeline1_streams1 CHASE_HIP_PIPELINE=1 CHASE_HIP_COMM_STREAMS=1" "pipeline0_streams2 CHASE_HIP_PIPELINE=0 CHASE_HIP_COMM_STREAMS=2"; do
+for v in "pipeline1_streams2 CHASE_HIP_PIPELINE=1 CHASE_HIP_COMM_STREAMS=2" "pipeline1_streams1 CHASE_HIP_PIPELINE=1 CHASE_HIP_COMM_STREAMS=1" "pipeline0_streams2 CHASE_HIP_PIPELINE=0 CHASE_HIP_COMM_STREAMS=2" "pipeline0_streams1 CHASE_HIP_PIPELINE=0 CHASE_HIP_COMM_STREAMS=1"; do
   set -- $v; name=$1; shift
   env CHASE_BENCH_FAKE_HOSTS=1 "$@" python3 bench.py --gpus 4 --workload cfg2 --steps 9 --warmup 0 --no-cpu-baseline --no-probe --no-autotune > ${OUT}_$name.json 2> ${OUT}_$name.log || { tail -5 ${OUT}_$name.log; exit 1; }
   python3 - ${OUT}_$name.json $name <<'PY'
