@@ -19,6 +19,17 @@ trial steps here are identical for every candidate.  The knobs can still be swit
 
 PANELS = (128, 256, 512)
 TIE = 0.01                      # relative margin inside which two settings count as equally fast
+# A solve is not only filter products: per full-width-equivalent product (one HEMM call; ~160 per solve whatever the size:
+# 9 iterations of degree ~20-36 on a shrinking block) it issues about 2.8 SMALL synchronous collectives (~450 per solve: Lanczos
+# scalars, agreement collectives, packed Gram / projection sums, residual sums).  A setting is judged by seconds per product
+# PLUS that many small-collective latencies: over RCCL's socket transport two communication streams make the filter 10 % faster
+# and every small collective 19 ms instead of 1 ms slower (profiles/r05_socket_rccl_streams.txt) - judged on the filter
+# alone the tuning would lock a setting that nearly doubles the solve (measured: 20.7 s against 12.4 s).
+SMALL_PER_PRODUCT = 2.8
+
+
+def cost(rec):
+    return rec["seconds"] + SMALL_PER_PRODUCT * rec.get("small_collective_us", 0.0) * 1e-6
 
 
 def plan(base, budget):
@@ -37,13 +48,15 @@ def plan(base, budget):
 
 
 def better(a, b):
-    """a, b: trial records {"seconds", "exposed_ms"}: is a strictly preferable to b?  Faster by more than the tie margin wins;
-    inside the margin the one with less exposed communication wins; equal on both, the incumbent (b) stays."""
-    if a["seconds"] < b["seconds"] * (1.0 - TIE):
+    """a, b: trial records {"seconds", "exposed_ms"[, "small_collective_us"]}: is a strictly preferable to b?  Cheaper (seconds
+    per product + the small collectives that come with it) by more than the tie margin wins; inside the margin the one with
+    less exposed communication wins; equal on both, the incumbent (b) stays."""
+    ca, cb = cost(a), cost(b)
+    if ca < cb * (1.0 - TIE):
         return True
-    if a["seconds"] > b["seconds"] * (1.0 + TIE):
+    if ca > cb * (1.0 + TIE):
         return False
-    return a["exposed_ms"] < b["exposed_ms"] * (1.0 - TIE) and a["seconds"] <= b["seconds"] * (1.0 + TIE)
+    return a["exposed_ms"] < b["exposed_ms"] * (1.0 - TIE) and ca <= cb * (1.0 + TIE)
 
 
 def tune(base, budget, measure):
@@ -84,6 +97,7 @@ def first_contact(s, ctx, grid, comm, nevex, budget=5, steps=2, log=None):
     A trial = `steps` pairs of full-width filter products (column -> row and row -> column, all-reduces included) between two
     (device sync + barrier) brackets; seconds = max over ranks."""
     import time
+    import numpy as np
     from .capi import lib, check
 
     def measure(setting):
@@ -108,14 +122,37 @@ def first_contact(s, ctx, grid, comm, nevex, budget=5, steps=2, log=None):
             e1, _ = grid.comm_exposed_ms()
         finally:
             check(lib.chase_hip_ctx_set_phase(ctx.h, 0), "set_phase")
-        sec, exp = comm.allreduce_max([dt, e1 - e0])
-        rec = {"seconds": sec / (2 * steps), "exposed_ms": exp / (2 * steps)}
+        # latency of a small synchronous collective, alternating between the two communicators like the solve does
+        from .dist import ROW, COL
+        groups = [g for g in (COL, ROW) if lib.chase_hip_grid_group_active(grid.h, g)]
+        small_us = 0.0
+        if groups:
+            scal = ctx.empty((64,), np.float64)
+            check(lib.chase_hip_memset(ctx.h, scal.ptr, 0, 64 * 8), "memset")
+            for g in groups:
+                check(lib.chase_hip_grid_allreduce(grid.h, g, scal.ptr, 64, 0), "allreduce")
+            ctx.sync()
+            comm.barrier()
+            t1 = time.perf_counter()
+            reps = 20
+            for _ in range(reps):
+                for g in groups:
+                    check(lib.chase_hip_grid_allreduce(grid.h, g, scal.ptr, 64, 0), "allreduce")
+            ctx.sync()
+            small_us = (time.perf_counter() - t1) / (reps * len(groups)) * 1e6
+            scal.free()
+        sec, exp, small_us = comm.allreduce_max([dt, e1 - e0, small_us])
+        rec = {"seconds": sec / (2 * steps), "exposed_ms": exp / (2 * steps), "small_collective_us": small_us}
+        rec["cost_seconds"] = cost(rec)
         if log:
-            log(f"autotune: {setting} -> {rec['seconds'] * 1e3:.1f} ms per full-width product, {rec['exposed_ms']:.1f} ms exposed")
+            log(f"autotune: {setting} -> {rec['seconds'] * 1e3:.1f} ms per full-width product, {rec['exposed_ms']:.1f} ms exposed, "
+                f"{small_us:.0f} us per small collective -> cost {rec['cost_seconds'] * 1e3:.1f} ms")
         return rec
 
     base = current_setting(s, grid)
     best, table = tune(base, budget, measure)
     apply_setting(s, grid, best)
-    return {"base": base, "chosen": best, "unit": "seconds per full-width distributed HEMM (max over ranks), one factor at a time",
+    return {"base": base, "chosen": best,
+            "unit": "cost = seconds per full-width distributed HEMM + %.1f x the latency of a small synchronous collective (max over "
+                    "ranks); one factor at a time" % SMALL_PER_PRODUCT,
             "trials": table}

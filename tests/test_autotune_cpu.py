@@ -55,3 +55,24 @@ def test_a_slower_candidate_never_replaces_a_faster_incumbent_whatever_it_expose
     assert A.better({"seconds": 0.98, "exposed_ms": 80.0}, {"seconds": 1.0, "exposed_ms": 5.0})
     assert A.better({"seconds": 1.0, "exposed_ms": 1.0}, {"seconds": 1.0, "exposed_ms": 5.0})
     assert not A.better({"seconds": 1.0, "exposed_ms": 5.0}, {"seconds": 1.0, "exposed_ms": 5.0})
+
+
+def test_small_collective_latency_vetoes_a_setting_that_only_speeds_up_the_filter():
+    """What RCCL's socket transport showed (profiles/r05_socket_rccl_streams.txt): two communication streams make the filter
+    products 10 % faster and every small synchronous collective 19 ms instead of 1 ms - a solve issues ~2.8 of those per
+    product, so the setting must lose; with xGMI-like latencies (60 vs 50 us) the same filter gain must win."""
+    def script2(lat2_us):
+        def measure(s):
+            if s["comm_streams"] == 2:
+                return {"seconds": 0.0527, "exposed_ms": 39.7, "small_collective_us": lat2_us}
+            return {"seconds": 0.0588, "exposed_ms": 41.7, "small_collective_us": 950.0 if lat2_us > 1000 else 50.0}
+        return measure
+    base = {"panel_cols": 256, "panel_rounds": 4, "comm_streams": 1}
+    best, table = A.tune(base, 5, script2(19000.0))
+    assert best["comm_streams"] == 1 and table[-1]["setting"]["comm_streams"] == 2 and not table[-1]["kept"]
+    best, table = A.tune(base, 5, script2(60.0))
+    assert best["comm_streams"] == 2 and table[-1]["kept"]
+    assert A.cost({"seconds": 0.05, "exposed_ms": 0, "small_collective_us": 1000.0}) == pytest.approx(0.05 + A.SMALL_PER_PRODUCT * 1e-3)
+
+
+import pytest  # noqa: E402
