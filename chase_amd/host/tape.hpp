@@ -42,7 +42,9 @@ struct ScalarTape {
         if (pos + 2 > data.size()) throw std::runtime_error("tape: replay ran past the end of the recording");
         const int tag = (int)data[pos];
         const std::size_t cnt = (std::size_t)data[pos + 1];
-        if (tag != (int)t || cnt != n || pos + 2 + cnt > data.size())
+        if (tag == (int)t && cnt == n && pos + 2 + cnt > data.size())
+            throw std::runtime_error("tape: the recording ends inside a frame (truncated tape)");
+        if (tag != (int)t || cnt != n)
             throw std::runtime_error("tape: replay diverged from the recording (frame " + std::to_string(tag) + "/" +
                                      std::to_string(cnt) + ", expected " + std::to_string((int)t) + "/" + std::to_string(n) + ")");
         const double* v = data.data() + pos + 2;
