@@ -26,8 +26,10 @@ def bse_diagonal(N, nev, dmin, dmax):
     return np.sqrt(dmin * dmin + (dmax * dmax - dmin * dmin) * i / (h - 1))
 
 
-def fullsize_rank(ctx, grid, comm, wl, nb, result, hash_replicas=True):
-    """One rank of the full-size solve; rank 0 leaves the record in `result` (a dict shared by the rank threads)."""
+def fullsize_rank(ctx, grid, comm, wl, nb, result, hash_replicas=True, perturb=None, device_rng=1):
+    """One rank of the full-size solve; rank 0 leaves the record in `result` (a dict shared by the rank threads).
+    perturb / device_rng: the oracle-pinned variant runs the UNPERTURBED matrix from the reference's start vectors
+    (mt19937(1337 + grid row) on the host, pchase_cpu.hpp:272-283) so that an independent implementation can be compared."""
     import bench as B
     from chase_amd import dist as cd
     N, cplx, nev, nex = B.WORKLOADS[wl]
@@ -41,10 +43,10 @@ def fullsize_rank(ctx, grid, comm, wl, nb, result, hash_replicas=True):
         s.set(device_rng=1, numlanczos=10, lanczositer=50)      # the reference's BSE settings (5_bse_benchmark / BSE test)
     else:
         dH = cd.gen_clement_local(ctx, N, cplx, rl, cl, grid.myrow, grid.mycol, scale=B.MATRIX_SCALE / N,
-                                  perturb=B.MATRIX_PERTURB)
+                                  perturb=B.MATRIX_PERTURB if perturb is None else perturb)
         ctx.sync()
         s = cd.DistSolver(ctx, grid, dH, N, nev, nex, cplx, nb, nb)
-        s.set(device_rng=1)
+        s.set(device_rng=device_rng)
     comm.barrier()
     t = time.perf_counter()
     st = s.solve()
@@ -83,6 +85,8 @@ def fullsize_rank(ctx, grid, comm, wl, nb, result, hash_replicas=True):
                       eigenvalues_bitwise_equal_on_all_ranks=bool(lam_equal and resid_equal),
                       eigenvector_replicas_bitwise_equal=(all(len(v) == 1 for v in rows.values()) if hash_replicas else None),
                       spectrum_check=None if pseudo else B.spectrum_check(lam, N, nev),
+                      max_abs_dev_from_analytic=(None if pseudo else
+                                                 float(np.max(np.abs(np.sort(lam) - (B.MATRIX_SCALE / N) * (-N + 2.0 * np.arange(nev)))))),
                       lambda_first=lam[:4].tolist(), lambda_last=lam[-2:].tolist(),
                       ascending=bool(np.all(np.diff(lam) >= 0)),
                       phases={k: st[k] for k in B.PHASES})
@@ -93,11 +97,11 @@ def fullsize_rank(ctx, grid, comm, wl, nb, result, hash_replicas=True):
     del dH
 
 
-def run_fullsize(wl, nprow, npcol, nb, hash_replicas=True, transport="shared"):
+def run_fullsize(wl, nprow, npcol, nb, hash_replicas=True, transport="shared", **kw):
     """transport "shared" (round 5): the rank threads' collectives are device-side sums / copies ordered by events between their
     streams (chase_hip_grid_create_shared) - asynchronous like RCCL; "host": staged through pinned host memory into the Python
     fabric (rounds 3-4; a fifth of the full-size wall time was that staging)"""
     from rank_threads import run_ranks
     result = {}
-    run_ranks(nprow, npcol, fullsize_rank, wl, nb, result, hash_replicas, transport=transport)
+    run_ranks(nprow, npcol, fullsize_rank, wl, nb, result, hash_replicas, transport=transport, **kw)
     return result

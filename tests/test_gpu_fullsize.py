@@ -19,6 +19,7 @@ from fullsize_scenarios import run_fullsize  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 OUT = os.path.join(ROOT, "gpurun_out")
+os.makedirs(OUT, exist_ok=True)
 
 
 def check(rec, iterations, vecs, tol_resid=1e-8):
@@ -41,6 +42,31 @@ def check(rec, iterations, vecs, tol_resid=1e-8):
 
 # (BASELINE configs[2] - N = 32768 real, nev = 1024, 2 x 2 block - runs at full size in tests/test_gpu_bench.py over REAL RCCL
 # communicators between four rank processes, the stronger form; round 4 also ran it here over the host fabric.)
+
+
+def test_cfg3_shape_at_full_size_takes_the_oracles_path():
+    """BASELINE configs[2]'s shape AT FULL SIZE (N = 32768 real, nev = 1024, nex = 256, 2 x 2 block grid) against an INDEPENDENT
+    implementation: the CPU oracle in its pChASECPU form solved the same problem here (35 minutes on 8 cores;
+    tests/golden/make_oracle_cfg3_fullsize.py -> oracle_cfg3_fullsize_unperturbed_2x2.json) - unperturbed Clement-type matrix x
+    100 / N, the reference's start vectors (mt19937(1337 + grid row) per block of local rows).  The HIP grid Impl must take the
+    oracle's path: same iterations, the filtered-vector count to 0.5 % (a last-bit difference in one residual moves one
+    column's degree by 2), the analytic spectrum, independent residuals.  Rounds 3-4 pinned the full-size counts to the
+    builder's own rehearsals only."""
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_cfg3_fullsize_unperturbed_2x2.json")))
+    assert (gold["N"], gold["nev"], gold["nex"], gold["grid"]) == (32768, 1024, 256, "2x2")
+    rec = run_fullsize("cfg3", 2, 2, 0, perturb=0.0, device_rng=0)
+    rec["oracle"] = {k: gold[k] for k in ("iterations", "filtered_vecs", "max_abs_dev_from_analytic", "max_resid")}
+    rec["workload"] = "cfg3_unperturbed_oracle_pinned"
+    with open(os.path.join(OUT, "fullsize_cfg3_oracle_pinned_2x2.json"), "w") as f:
+        json.dump(rec, f)
+    print(json.dumps(rec), flush=True)
+    assert rec["locked"] >= rec["nev"]
+    assert rec["iterations"] == gold["iterations"], (rec["iterations"], gold["iterations"])
+    assert abs(rec["filtered_vecs"] - gold["filtered_vecs"]) <= 0.005 * gold["filtered_vecs"], (rec["filtered_vecs"], gold["filtered_vecs"])
+    assert rec["max_abs_dev_from_analytic"] < 1e-8 and gold["max_abs_dev_from_analytic"] < 1e-8      # both on the exact spectrum
+    assert rec["max_resid"] <= 1e-8 and rec["max_resid_recomputed"] <= 1e-8
+    assert rec["pairs_converged_by_solver_but_recomputed_above_tol"] == 0
+    assert rec["eigenvalues_bitwise_equal_on_all_ranks"] and rec["eigenvector_replicas_bitwise_equal"]
 
 
 def test_cfg5_bse_n32768_nev256_block_4x2():
