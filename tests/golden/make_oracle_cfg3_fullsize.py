@@ -22,17 +22,27 @@ from oracle import chase_oracle as O  # noqa: E402
 
 N, nev, nex = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (32768, 1024, 256)
 out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "tests", "golden", "oracle_cfg3_fullsize_unperturbed_2x2.json")
+# optional: another grid - number of grid rows and the block size of a block-cyclic row distribution (0 = block layout); only the
+# grid ROWS matter to the oracle (they decide which rows a start-vector stream fills)
+nprow = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+nb = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 t0 = time.time()
 H = O.clement(N, False, perturb=0)
 H *= 100.0 / N
-rows = [np.arange(0, N // 2), np.arange(N // 2, N)]            # 2 x 2 block layout: grid row i owns rows [i N/2, (i+1) N/2)
+if nb == 0:
+    assert N % nprow == 0
+    rows = [np.arange(i * (N // nprow), (i + 1) * (N // nprow)) for i in range(nprow)]      # block layout: contiguous row blocks
+else:
+    g = np.arange(N)
+    rows = [g[(g // nb) % nprow == i] for i in range(nprow)]                                   # block-cyclic (distMatrix.hpp:44-67)
 k = O.OracleCPU(H, nev, nex, grid_rows=rows)
 del H
 st = O.solve(k)
 lam = k.ritzv[:nev].copy()
 exact = (100.0 / N) * (-N + 2.0 * np.arange(nev))
 rec = {"what": "oracle (pChASECPU form, 2x2 block grid) on the unperturbed Clement-type matrix x 100/N",
-       "N": N, "nev": nev, "nex": nex, "grid": "2x2", "layout": "block", "tol": k.config.tol, "deg": k.config.deg,
+       "N": N, "nev": nev, "nex": nex, "grid": "2x2" if (nprow, nb) == (2, 0) else "%dx*" % nprow,
+       "layout": "block" if nb == 0 else "block-cyclic nb=%d" % nb, "grid_rows": nprow, "tol": k.config.tol, "deg": k.config.deg,
        "iterations": int(st["iterations"]), "filtered_vecs": int(st["filtered_vecs"]),
        "max_abs_dev_from_analytic": float(np.max(np.abs(np.sort(lam) - exact))),
        "max_resid": float(np.max(k.resid[:nev])), "lambda_first": lam[:4].tolist(), "lambda_last": lam[-2:].tolist(),

@@ -44,20 +44,25 @@ def check(rec, iterations, vecs, tol_resid=1e-8):
 # communicators between four rank processes, the stronger form; round 4 also ran it here over the host fabric.)
 
 
-def test_cfg3_shape_at_full_size_takes_the_oracles_path():
+@pytest.mark.parametrize("nprow,npcol,nb,fixture", [(2, 2, 0, "oracle_cfg3_fullsize_unperturbed_2x2.json"),
+                                                    (4, 2, 64, "oracle_cfg3_fullsize_unperturbed_4x2_bc64.json")])
+def test_cfg3_shape_at_full_size_takes_the_oracles_path(nprow, npcol, nb, fixture):
     """BASELINE configs[2]'s shape AT FULL SIZE (N = 32768 real, nev = 1024, nex = 256, 2 x 2 block grid) against an INDEPENDENT
     implementation: the CPU oracle in its pChASECPU form solved the same problem here (35 minutes on 8 cores;
-    tests/golden/make_oracle_cfg3_fullsize.py -> oracle_cfg3_fullsize_unperturbed_2x2.json) - unperturbed Clement-type matrix x
-    100 / N, the reference's start vectors (mt19937(1337 + grid row) per block of local rows).  The HIP grid Impl must take the
+    tests/golden/make_oracle_cfg3_fullsize.py -> oracle_cfg3_fullsize_unperturbed_*.json) - unperturbed Clement-type matrix x
+    100 / N, the reference's start vectors (mt19937(1337 + grid row) per block of local rows) - once for the 2 x 2 block grid of
+    BASELINE configs[2] and once for the 4 x 2 block-cyclic (nb = 64) grid of configs[3] (another start block: the grid rows
+    decide which rows a stream fills).  The HIP grid Impl must take the
     oracle's path COUNT FOR COUNT: same iterations, same number of filtered vectors, the analytic spectrum, independent
     residuals.  Rounds 3-4 pinned the full-size counts to the
     builder's own rehearsals only."""
-    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_cfg3_fullsize_unperturbed_2x2.json")))
-    assert (gold["N"], gold["nev"], gold["nex"], gold["grid"]) == (32768, 1024, 256, "2x2")
-    rec = run_fullsize("cfg3", 2, 2, 0, perturb=0.0, device_rng=0)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", fixture)))
+    assert (gold["N"], gold["nev"], gold["nex"]) == (32768, 1024, 256)
+    assert gold.get("grid_rows", 2) == nprow and gold["layout"] == ("block" if nb == 0 else "block-cyclic nb=%d" % nb)
+    rec = run_fullsize("cfg3", nprow, npcol, nb, perturb=0.0, device_rng=0)
     rec["oracle"] = {k: gold[k] for k in ("iterations", "filtered_vecs", "max_abs_dev_from_analytic", "max_resid")}
     rec["workload"] = "cfg3_unperturbed_oracle_pinned"
-    with open(os.path.join(OUT, "fullsize_cfg3_oracle_pinned_2x2.json"), "w") as f:
+    with open(os.path.join(OUT, f"fullsize_cfg3_oracle_pinned_{nprow}x{npcol}.json"), "w") as f:
         json.dump(rec, f)
     print(json.dumps(rec), flush=True)
     assert rec["locked"] >= rec["nev"]
