@@ -40,7 +40,8 @@ del H
 st = O.solve(k)
 lam = k.ritzv[:nev].copy()
 exact = (100.0 / N) * (-N + 2.0 * np.arange(nev))
-rec = {"what": "oracle (pChASECPU form, 2x2 block grid) on the unperturbed Clement-type matrix x 100/N",
+rec = {"what": "oracle (pChASECPU form, %d grid rows, %s) on the unperturbed Clement-type matrix x 100/N"
+               % (nprow, "block layout" if nb == 0 else "block-cyclic nb = %d" % nb),
        "N": N, "nev": nev, "nex": nex, "grid": "2x2" if (nprow, nb) == (2, 0) else "%dx*" % nprow,
        "layout": "block" if nb == 0 else "block-cyclic nb=%d" % nb, "grid_rows": nprow, "tol": k.config.tol, "deg": k.config.deg,
        "iterations": int(st["iterations"]), "filtered_vecs": int(st["filtered_vecs"]),
