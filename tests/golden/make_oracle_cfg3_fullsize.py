@@ -26,8 +26,9 @@ out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "tests", "golden"
 # grid ROWS matter to the oracle (they decide which rows a start-vector stream fills)
 nprow = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 nb = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+cplx = len(sys.argv) > 7 and sys.argv[7] == "z"        # complex Hermitian twin (bench.py's cfg3c shape): 4 x the flops, 17 GB matrix
 t0 = time.time()
-H = O.clement(N, False, perturb=0)
+H = O.clement(N, cplx, perturb=0)
 H *= 100.0 / N
 if nb == 0:
     assert N % nprow == 0
@@ -42,7 +43,7 @@ lam = k.ritzv[:nev].copy()
 exact = (100.0 / N) * (-N + 2.0 * np.arange(nev))
 rec = {"what": "oracle (pChASECPU form, %d grid rows, %s) on the unperturbed Clement-type matrix x 100/N"
                % (nprow, "block layout" if nb == 0 else "block-cyclic nb = %d" % nb),
-       "N": N, "nev": nev, "nex": nex, "grid": "2x2" if (nprow, nb) == (2, 0) else "%dx*" % nprow,
+       "N": N, "nev": nev, "nex": nex, "complex": bool(cplx), "grid": "2x2" if (nprow, nb) == (2, 0) else "%dx*" % nprow,
        "layout": "block" if nb == 0 else "block-cyclic nb=%d" % nb, "grid_rows": nprow, "tol": k.config.tol, "deg": k.config.deg,
        "iterations": int(st["iterations"]), "filtered_vecs": int(st["filtered_vecs"]),
        "max_abs_dev_from_analytic": float(np.max(np.abs(np.sort(lam) - exact))),
