@@ -59,10 +59,10 @@ def test_cfg3_shape_at_full_size_takes_the_oracles_path(nprow, npcol, nb, fixtur
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", fixture)))
     assert (gold["N"], gold["nev"], gold["nex"]) == (32768, 1024, 256)
     assert gold.get("grid_rows", 2) == nprow and gold["layout"] == ("block" if nb == 0 else "block-cyclic nb=%d" % nb)
-    rec = run_fullsize("cfg3", nprow, npcol, nb, perturb=0.0, device_rng=0)
+    rec = run_fullsize("cfg3c" if gold.get("complex") else "cfg3", nprow, npcol, nb, perturb=0.0, device_rng=0)
     rec["oracle"] = {k: gold[k] for k in ("iterations", "filtered_vecs", "max_abs_dev_from_analytic", "max_resid")}
     rec["workload"] = "cfg3_unperturbed_oracle_pinned"
-    with open(os.path.join(OUT, f"fullsize_cfg3_oracle_pinned_{nprow}x{npcol}.json"), "w") as f:
+    with open(os.path.join(OUT, f"fullsize_cfg3{'c' if gold.get('complex') else ''}_oracle_pinned_{nprow}x{npcol}.json"), "w") as f:
         json.dump(rec, f)
     print(json.dumps(rec), flush=True)
     assert rec["locked"] >= rec["nev"]
