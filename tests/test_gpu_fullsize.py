@@ -45,14 +45,16 @@ def check(rec, iterations, vecs, tol_resid=1e-8):
 
 
 @pytest.mark.parametrize("nprow,npcol,nb,fixture", [(2, 2, 0, "oracle_cfg3_fullsize_unperturbed_2x2.json"),
-                                                    (4, 2, 64, "oracle_cfg3_fullsize_unperturbed_4x2_bc64.json")])
+                                                    (4, 2, 64, "oracle_cfg3_fullsize_unperturbed_4x2_bc64.json"),
+                                                    (2, 2, 0, "oracle_cfg3c_fullsize_unperturbed_2x2.json")])
 def test_cfg3_shape_at_full_size_takes_the_oracles_path(nprow, npcol, nb, fixture):
     """BASELINE configs[2]'s shape AT FULL SIZE (N = 32768 real, nev = 1024, nex = 256, 2 x 2 block grid) against an INDEPENDENT
     implementation: the CPU oracle in its pChASECPU form solved the same problem here (35 minutes on 8 cores;
     tests/golden/make_oracle_cfg3_fullsize.py -> oracle_cfg3_fullsize_unperturbed_*.json) - unperturbed Clement-type matrix x
     100 / N, the reference's start vectors (mt19937(1337 + grid row) per block of local rows) - once for the 2 x 2 block grid of
-    BASELINE configs[2] and once for the 4 x 2 block-cyclic (nb = 64) grid of configs[3] (another start block: the grid rows
-    decide which rows a stream fills).  The HIP grid Impl must take the
+    BASELINE configs[2], once for the 4 x 2 block-cyclic (nb = 64) grid of configs[3] (another start block: the grid rows
+    decide which rows a stream fills), and once COMPLEX (bench.py's cfg3c shape: the three-multiplication filter kernel of the
+    headline against numpy's zgemm; 105 minutes of oracle time).  The HIP grid Impl must take the
     oracle's path COUNT FOR COUNT: same iterations, same number of filtered vectors, the analytic spectrum, independent
     residuals.  Rounds 3-4 pinned the full-size counts to the
     builder's own rehearsals only."""
