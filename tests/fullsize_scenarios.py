@@ -97,6 +97,46 @@ def fullsize_rank(ctx, grid, comm, wl, nb, result, hash_replicas=True, perturb=N
     del dH
 
 
+def pseudo_oracle_rank(ctx, grid, comm, N, nev, nex, bse, result):
+    """One rank of the ORACLE-PINNED full-size pseudo-Hermitian solve: the shard of oracle.synthetic_bse_block (a matrix every rank
+    can build for itself, and the CPU oracle as a whole), block layout, the reference's start vectors (host mt19937(1337 + grid
+    row), global lower half damped: pchase_cpu.hpp:272-311), the reference's BSE settings."""
+    from chase_amd import dist as cd
+    from oracle import chase_oracle as O
+    rl, cl = cd.Layout(N, 0, grid.nprow), cd.Layout(N, 0, grid.npcol)
+    rows, cols = rl.globals_of(grid.myrow), cl.globals_of(grid.mycol)
+    blk = np.empty((len(rows), len(cols)), dtype=np.complex128, order="F")
+    for r0 in range(0, len(rows), 512):                        # in row chunks: the index / hash temporaries are chunk-sized
+        blk[r0:r0 + 512, :] = O.synthetic_bse_block(rows[r0:r0 + 512], cols, N, **bse)
+    dH = ctx.array(blk)
+    del blk
+    s = cd.DistPseudoSolver(ctx, grid, dH, N, nev, nex, True, 0, 0)
+    s.set(numlanczos=10, lanczositer=50)                        # host RNG: device_rng stays off
+    comm.barrier()
+    t = time.perf_counter()
+    st = s.solve()
+    ctx.sync()
+    comm.barrier()
+    wall = time.perf_counter() - t
+    lam, resid = s.ritzv[:nev].copy(), s.resid()[:nev].copy()
+    digest = s.hash_V(nev)
+    resid_re = s.recompute_residuals(nev, lam)
+    everyone = comm.all_gather_object((grid.myrow, grid.mycol, lam, digest, resid_re))
+    if comm.rank == 0:
+        rows_d = {}
+        for (i, j, _, dg, _) in everyone:
+            rows_d.setdefault(i, set()).add(dg)
+        result.update(N=N, nev=nev, nex=nex, grid=f"{grid.nprow}x{grid.npcol}", iterations=st["iterations"],
+                      filtered_vecs=st["filtered_vecs"], locked=st["locked"], wall_seconds=wall, max_resid=float(np.max(resid)),
+                      max_resid_recomputed=float(np.max(np.stack([e[4] for e in everyone]))),
+                      lambda_first=lam[:6].tolist(), lambda_last=lam[-2:].tolist(), lambda_sum=float(np.sum(lam)),
+                      eigenvalues_bitwise_equal_on_all_ranks=all(np.array_equal(everyone[0][2], e[2]) for e in everyone),
+                      eigenvector_replicas_bitwise_equal=all(len(v) == 1 for v in rows_d.values()),
+                      phases={k: st[k] for k in ("t_all", "t_lanczos", "t_filter", "t_qr", "t_rr", "t_resid")})
+    s.close()
+    dH.free()
+
+
 def run_fullsize(wl, nprow, npcol, nb, hash_replicas=True, transport="shared", **kw):
     """transport "shared" (round 5): the rank threads' collectives are device-side sums / copies ordered by events between their
     streams (chase_hip_grid_create_shared) - asynchronous like RCCL; "host": staged through pinned host memory into the Python
