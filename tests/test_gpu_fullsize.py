@@ -108,9 +108,13 @@ def test_cfg5_shape_at_full_size_against_the_oracle(fixture):
     assert rec["eigenvalues_bitwise_equal_on_all_ranks"] and rec["eigenvector_replicas_bitwise_equal"]
 
 
+@pytest.mark.skipif(not os.environ.get("CHASE_TEST_EXTENDED"),
+                    reason="superseded in the default suite by the oracle-pinned solve of the same size, grid and path above "
+                           "(22 s; CHASE_TEST_EXTENDED=1 runs it; last record: profiles/r05_fullsize_cfg5_4x2.json)")
 def test_cfg5_bse_n32768_nev256_block_4x2():
-    """BASELINE configs[4]: N = 32768 pseudo-Hermitian Bethe-Salpeter, nev = 256, eight ranks (4 x 2, block-block: the only
-    layout the reference supports for pseudo-Hermitian matrices, Impl/pchase_gpu/pchase_gpu.hpp:165-178)"""
+    """BASELINE configs[4] with bench.py's own workload (device-generated matrix and start block): N = 32768 pseudo-Hermitian
+    Bethe-Salpeter, nev = 256, eight ranks (4 x 2, block-block: the only layout the reference supports for pseudo-Hermitian
+    matrices, Impl/pchase_gpu/pchase_gpu.hpp:165-178)"""
     rec = run_fullsize("cfg5", 4, 2, 0)
     check(rec, 11, 172732)
     assert rec["lambda_first"][0] > 0.0                                  # the positive half of the +- spectrum
