@@ -606,7 +606,27 @@ struct chase_hip_fabric {
 
 static int fab_fail(const char* what) { return set_error(CHASE_HIP_ECOMM, what); }
 
+static int fabric_collective_body(chase_hip_grid* g, int mode, int group, void* dev, size_t count, int root);
+static int fabric_sendrecv_body(chase_hip_grid* g, int group, const void* sendbuf, size_t sendcount, int peer_send, void* recvbuf,
+                                size_t recvcount, int peer_recv);
+// a member that fails for a reason of its own (a HIP error on its stream, a failed allocation) must not leave the others waiting
+// for it until the time-out: whatever fails inside the fabric fails the fabric
+static int fab_mark(chase_hip_fabric* F, int rc)
+{
+    if (rc) { std::lock_guard<std::mutex> lk(F->mu); F->failed = true; F->cv.notify_all(); }
+    return rc;
+}
 static int fabric_collective(chase_hip_grid* g, int mode, int group, void* dev, size_t count, int root)
+{
+    return fab_mark(g->fabric, fabric_collective_body(g, mode, group, dev, count, root));
+}
+static int fabric_sendrecv(chase_hip_grid* g, int group, const void* sendbuf, size_t sendcount, int peer_send, void* recvbuf,
+                           size_t recvcount, int peer_recv)
+{
+    return fab_mark(g->fabric, fabric_sendrecv_body(g, group, sendbuf, sendcount, peer_send, recvbuf, recvcount, peer_recv));
+}
+
+static int fabric_collective_body(chase_hip_grid* g, int mode, int group, void* dev, size_t count, int root)
 {
     chase_hip_fabric* F = g->fabric;
     chase_hip_ctx* c = g->ctx;
@@ -657,8 +677,8 @@ static int fabric_collective(chase_hip_grid* g, int mode, int group, void* dev, 
     return 0;
 }
 
-static int fabric_sendrecv(chase_hip_grid* g, int group, const void* sendbuf, size_t sendcount, int peer_send, void* recvbuf,
-                           size_t recvcount, int peer_recv)
+static int fabric_sendrecv_body(chase_hip_grid* g, int group, const void* sendbuf, size_t sendcount, int peer_send, void* recvbuf,
+                                size_t recvcount, int peer_recv)
 {
     chase_hip_fabric* F = g->fabric;
     FabGroup& G = F->group(group, g->myrow, g->mycol);
