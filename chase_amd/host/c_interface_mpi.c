@@ -11,7 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include "../../include/chase_c_interface.h"
+#include "../../include/chase_c_interface_mpi.h"
 #include "../../include/chase_hip.h"
 #include "../../include/chase_hip_grid.h"
 

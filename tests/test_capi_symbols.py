@@ -33,6 +33,14 @@ def test_mpi_front_end_exports_the_reference_signatures():
     if not os.path.exists(path):
         pytest.skip("no MPI on this box: front end not built")
     out = os.popen(f"nm -D --defined-only {path}").read()
+    # every entry point include/chase_c_interface_mpi.h declares (the front end includes that header: a signature that differs
+    # from its declaration does not compile)
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "chase_c_interface_mpi.h")).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(p[dz]chase_init[a-z_]*)\s*\(", txt)))
+    assert len(declared) == 24, declared
+    for n in declared:
+        assert f" T {n}\n" in out, n
+    assert '#include "../../include/chase_c_interface_mpi.h"' in open(os.path.join(ROOT, "chase_amd", "host", "c_interface_mpi.c")).read()
     for n in ("pdchase_init_", "pdchase_init_internal_", "pzchase_init_", "pzchase_init_internal_", "pzchase_init_pseudo_",
               "pdchase_init_blockcyclic_", "pdchase_init_blockcyclic_internal_", "pzchase_init_blockcyclic_",
               "pzchase_init_blockcyclic_internal_", "pzchase_init_pseudo_blockcyclic_"):
