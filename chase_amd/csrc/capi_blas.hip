@@ -664,6 +664,8 @@ int chase_hip_pseudo_rr_small(chase_hip_ctx* c, int cplx, int n, void* A_dev, vo
     (void)hipSetDevice(c->device);      // entry points may be called with another device current
     if (c->oplog_on) c->oplog_add("pseudo_rr_small", n, 0, 0, 0);
     if (n <= 0) return 0;
+    // one line for the whole dense core: its inner sequence ends early when A does not factorise (data-dependent)
+    struct Mute { chase_hip_ctx* c; Mute(chase_hip_ctx* x) : c(x) { ++c->oplog_mute; } ~Mute() { --c->oplog_mute; } } mute(c);
     const size_t bytes = (size_t)n * n * sizeof(double) * ept_of(cplx);
     RCCHK(c->ensure_hstage(2 * bytes));
     double* hA = (double*)c->hstage;
@@ -719,6 +721,10 @@ int chase_hip_heevd_host(int cplx, int n, void* A_host, long lda, double* w_host
 /* host-only helper: all eigenpairs of a symmetric tridiagonal matrix (reference lapackpp::t_stemr, cpu/lanczos.hpp:188) */
 int chase_hip_stemr_host(int n, double* d, double* e, double* w, double* Z, int ldz)
 {
+    // LAPACK's MRRR does not terminate on every non-finite input: a Lanczos recurrence that broke down is an error, not a hang
+    for (int i = 0; i < n; ++i)
+        if (!std::isfinite(d[i]) || (i + 1 < n && !std::isfinite(e[i])))
+            return set_error(CHASE_HIP_EINVAL, "stemr: the tridiagonal matrix has non-finite entries (Lanczos breakdown?)");
     return host_stemr(n, d, e, w, Z, ldz);
 }
 int chase_hip_stedc(chase_hip_ctx* c, int n, const double* d_host, const double* e_host, double* w_host, double* Z_dev, long ldz)

@@ -30,6 +30,11 @@ struct HipImplExtras {
     // falling back to Householder (single-rank replay follows the recording's QR variants, tape.hpp); -1: by data (default)
     virtual void set_forced_qr(int) {}
     virtual std::size_t forced_qr_retries() const { return 0; }
+    // single-rank replay of the pseudo-Hermitian solve: the lone rank's projected matrices are partial sums - when Q^H S H Q does
+    // not factorise, Rayleigh-Ritz runs the same operators on the identity instead of throwing; a Lanczos tridiagonal the host
+    // eigensolver rejects yields zeros (the driver reads the tape's numbers either way)
+    virtual void set_replay_tolerant(bool) {}
+    virtual std::size_t replay_tolerated() const { return 0; }
     // phase marker of the profiler ranges (CHASE_HIP_ROCTX=1, roctx.hpp): nothing to implement
 };
 

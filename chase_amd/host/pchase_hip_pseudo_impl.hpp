@@ -146,7 +146,10 @@ public:
         R thld_hi = 1e8, thld_lo = 2e1;
         if (const char* s = std::getenv("CHASE_CHOLQR1_THLD")) thld_lo = std::atof(s);
         this->last_qr_variant_ = 0;
-        if (disable == 1 && cond != (R)1.0) {
+        if (this->forced_qr_ >= 0) {                            // single-rank replay: the recording's variant (set_forced_qr)
+            if (this->forced_qr_ == 0) this->householder();
+            else { this->last_qr_variant_ = this->forced_qr_; this->cholqr_dist(this->forced_qr_); }
+        } else if (disable == 1 && cond != (R)1.0) {
             this->householder();
         } else {
             const int variant = (cond > thld_hi) ? 3 : (cond < thld_lo ? 1 : 2);
@@ -185,6 +188,15 @@ public:
         this->allreduce_packed_upper(M, n, CHASE_HIP_COL);
         int info = chase_hip_pseudo_rr_small(this->ctx_, CP, (int)n, A, M, ritzv);
         P::coll(chase_hip_grid_agree_max(this->grid_, &info));
+        if (info > 0 && this->replay_tolerant_) {
+            // replay only (set_replay_tolerant): the lone rank's A is a partial sum and need not be positive definite - the same
+            // dense core once more on A = I (kept out of the operator log: the real rank has no such second pass)
+            struct Mute { chase_hip_ctx* c; Mute(chase_hip_ctx* x) : c(x) { chase_hip_ctx_oplog_mute(c, 1); } ~Mute() { chase_hip_ctx_oplog_mute(c, -1); } } mute(this->ctx_);
+            hip_ok(chase_hip_set_identity(this->ctx_, CP, (int)n, A, (long)n), "set_identity");
+            // (M = Q^H S Q is untouched: the dense core returns before it writes M when the factorisation of A fails)
+            info = chase_hip_pseudo_rr_small(this->ctx_, CP, (int)n, A, M, ritzv);
+            ++this->replay_tolerated_;
+        }
         if (info > 0) throw std::runtime_error("pChaseHipPseudo::RR: Q^H S H Q is not positive definite (potrf info " +
                                                std::to_string(info) + ")");
         hip_ok(info, "pseudo_rr_small");
@@ -317,14 +329,26 @@ private:
             chase_hip_free(ctx, blk);
             blk = nullptr;
             std::vector<double> dd(M), ee(M), w(M), Z(M * M);
+            bool broke = false;
             for (std::size_t i = 0; i < nv; ++i) {
                 for (std::size_t k = 0; k < M; ++k) { dd[k] = d[k + M * i]; ee[k] = (k + 1 < M) ? e[k + M * i] : 0.0; }
-                hip_ok(chase_hip_stemr_host((int)M, dd.data(), ee.data(), w.data(), Z.data(), (int)M), "stemr");
+                const int rc_stemr = chase_hip_stemr_host((int)M, dd.data(), ee.data(), w.data(), Z.data(), (int)M);
+                if (rc_stemr != 0 && this->replay_tolerant_) {              // replay: the tape's numbers are what the driver reads
+                    std::fill(w.begin(), w.end(), 0.0); std::fill(Z.begin(), Z.end(), 0.0); ++this->replay_tolerated_;
+                    broke = true;
+                } else hip_ok(rc_stemr, "stemr");
                 for (std::size_t k = 0; k < M; ++k) {
                     theta[k + i * M] = w[k];
                     if (Tau) Tau[k + i * M] = std::abs(Z[k * M]) * std::abs(Z[k * M]);
                 }
                 if (ritzV) std::memcpy(ritzV, Z.data(), M * M * sizeof(double));
+            }
+            if (broke && store) {
+                // replay only: a recurrence normalised by partial sums can overflow; the Lanczos vectors it left in the block
+                // are replaced by N(0,1) so that what follows runs on finite numbers (not in the operator log)
+                struct Mute { chase_hip_ctx* c; Mute(chase_hip_ctx* x) : c(x) { chase_hip_ctx_oplog_mute(c, 1); } ~Mute() { chase_hip_ctx_oplog_mute(c, -1); } } mute(ctx);
+                hip_ok(chase_hip_fill_normal(ctx, CP, ml, (int)std::min<std::size_t>(std::max(M, nv), this->nc_), this->dV1_, (long)m, 0, 0,
+                                             (long)m, 4242ULL), "fill_normal");
             }
             std::vector<R> pack(theta, theta + M * nv);                         // identical spectral estimates on every rank
             if (Tau) pack.insert(pack.end(), Tau, Tau + M * nv);

@@ -239,6 +239,7 @@ int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* out)
         else if (name == "resd_rechecked") *out = (double)s->ex->resd_rechecked();
         else if (name == "tape_qr_mismatches") *out = (double)s->tape.qr_variant_mismatches;   // of the last replay
         else if (name == "tape_qr_retries") *out = (double)s->ex->forced_qr_retries();   // shifted re-factorisations, replay
+        else if (name == "tape_tolerated") *out = (double)s->ex->replay_tolerated();    // pseudo-Hermitian replay: tolerated cores
         else if (name == "tape_position") *out = (double)s->tape.pos;
         else if (name == "tape_size") *out = (double)s->tape.data.size();
         else if (name == "iterations") *out = (double)s->stats.iterations;          // of the last solve
@@ -264,8 +265,15 @@ int chase_hip_solver_solve(chase_hip_solver* s, int record_trace)
     s->trace.enabled = record_trace != 0;
     return guarded("solve", [&] {
         // chase::Solve / chase::Solve_pseudo (algorithm/algorithm.hpp:345-364)
-        if (s->pseudo) {
-            if (s->tape_mode) throw std::invalid_argument("the pseudo-Hermitian driver is not taped");
+        if (s->pseudo && s->tape_mode) {
+            if (s->cplx) {
+                TapeKernel<zc> tk(s->z.get(), s->ex, &s->tape, (TapeKernel<zc>::Mode)s->tape_mode);
+                Algorithm<zc, ChaseBase<zc>>::solve_pseudo(&tk, &s->stats, &s->trace);
+            } else {
+                TapeKernel<double> tk(s->d.get(), s->ex, &s->tape, (TapeKernel<double>::Mode)s->tape_mode);
+                Algorithm<double, ChaseBase<double>>::solve_pseudo(&tk, &s->stats, &s->trace);
+            }
+        } else if (s->pseudo) {
             if (s->cplx) Algorithm<zc, ChaseBase<zc>>::solve_pseudo(s->z.get(), &s->stats, &s->trace);
             else Algorithm<double, ChaseBase<double>>::solve_pseudo(s->d.get(), &s->stats, &s->trace);
         } else if (s->tape_mode) {
@@ -287,11 +295,10 @@ int chase_hip_solver_solve(chase_hip_solver* s, int record_trace)
 /* Scalar tape of chase_hip_solver_solve (chase_amd/host/tape.hpp): mode 1 = the next solves RECORD everything the kernel
  * tells the driver (Ritz values, residuals, Lanczos outputs, the QR variant taken), mode 2 = the next solves REPLAY the loaded
  * tape: the kernel does all of its device work, the driver sees the recorded numbers and therefore issues the recorded call
- * sequence; 0 = off.  Hermitian solves only. */
+ * sequence; 0 = off.  Both drivers (chase::Solve, chase::Solve_pseudo). */
 int chase_hip_solver_tape_mode(chase_hip_solver* s, int mode)
 {
     if (!s || mode < 0 || mode > 2) return chase_hip::set_error(CHASE_HIP_EINVAL, "tape_mode: 0, 1 or 2");
-    if (mode && s->pseudo) return chase_hip::set_error(CHASE_HIP_EINVAL, "tape_mode: the pseudo-Hermitian driver is not taped");
     s->tape_mode = mode;
     return 0;
 }

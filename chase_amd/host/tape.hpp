@@ -12,7 +12,8 @@
 // the workload drives pChaseHip<T> on a loopback grid (chase_hip_grid_create_loopback) with that rank's local block shapes
 // (Impl/pchase_gpu/pchase_gpu.hpp:1550-1700 and linalg/internal/nccl/hemm.hpp:25-399 are what such a rank executes in the
 // reference).  The replayed kernel's numbers are wrong by construction; its launches, shapes and time are the real rank's.
-// Hermitian solves only (chase::Solve); the pseudo-Hermitian driver is not taped.
+// Both drivers (chase::Solve, chase::Solve_pseudo).  A replayed pseudo-Hermitian kernel is told to tolerate what its partial sums
+// may bring (HipImplExtras::set_replay_tolerant: a projected matrix that does not factorise).
 #pragma once
 #include <cstddef>
 #include <cstring>
@@ -63,17 +64,17 @@ public:
     {
         static_assert(sizeof(R) == sizeof(double), "fp64 only");
         if (!inner || !tape) throw std::invalid_argument("TapeKernel: null argument");
-        if (inner->isPseudoHerm()) throw std::invalid_argument("TapeKernel: the pseudo-Hermitian driver is not taped");
         if (mode == RECORD) { tape->data.clear(); tape->rewind(); }
-        else tape->rewind();
+        else { tape->rewind(); if (ex_) ex_->set_replay_tolerant(true); }
     }
-    ~TapeKernel() override { if (ex_) { ex_->set_forced_recheck(-1); ex_->set_forced_qr(-1); } }
+    ~TapeKernel() override { if (ex_) { ex_->set_forced_recheck(-1); ex_->set_forced_qr(-1); ex_->set_replay_tolerant(false); } }
 
     // ---- the calls whose host outputs steer the driver ------------------------------------------------------------------
     void RR(R* ritzv, std::size_t block) override
     {
         k_->RR(ritzv, block);
-        exchange(ScalarTape::RR, ritzv, block);
+        // the pseudo-Hermitian RR hands back both halves of the +- spectrum (2 * block values, rayleighRitz_v2)
+        exchange(ScalarTape::RR, ritzv, k_->isPseudoHerm() ? 2 * block : block);
     }
     void Resd(R* ritzv, R* resd, std::size_t fixednev) override
     {

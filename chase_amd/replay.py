@@ -26,10 +26,23 @@ def record_tape(ctx, workload, n_override=0, log=None):
     N, cplx, nev, nex = B.WORKLOADS[workload]
     if n_override:
         N = n_override
-    dH = ctx.gen_clement(N, cplx, scale=B.MATRIX_SCALE / N, perturb=B.MATRIX_PERTURB, seed=42)
-    ctx.sync()
-    s = Solver(ctx, None, nev, nex, h_on_device_ptr=dH.ptr, N=N, cplx=cplx)
-    s.set(device_rng=1)
+    pseudo = workload in B.PSEUDO_WORKLOADS
+    grid = None
+    if pseudo:
+        # the pseudo-Hermitian workload always runs the grid Impl (bench.py): its single-GPU solve is that Impl on a 1 x 1 grid,
+        # where a loopback transport is exact (every group has one member)
+        from . import dist as cd
+        grid = cd.Grid(ctx, 1, 1, 0, transport="loopback")
+        lay = cd.Layout(N, 0, 1)
+        dH = cd.gen_bse_local(ctx, N, cplx, lay, lay, 0, 0, **B.BSE_MATRIX)
+        ctx.sync()
+        s = cd.DistPseudoSolver(ctx, grid, dH, N, nev, nex, cplx, 0, 0)
+        s.set(device_rng=1, numlanczos=10, lanczositer=50)
+    else:
+        dH = ctx.gen_clement(N, cplx, scale=B.MATRIX_SCALE / N, perturb=B.MATRIX_PERTURB, seed=42)
+        ctx.sync()
+        s = Solver(ctx, None, nev, nex, h_on_device_ptr=dH.ptr, N=N, cplx=cplx)
+        s.set(device_rng=1)
     tape_mode(s, 1)
     if log:
         s.set_iteration_hook(lambda it, f, l, u: log(f"record: iteration {it}: {f} vectors filtered, {l} locked") or False)
@@ -39,8 +52,8 @@ def record_tape(ctx, workload, n_override=0, log=None):
     wall = time.perf_counter() - t0
     tape = tape_get(s)
     lam, resid = s.ritzv[:nev].copy(), s.resid()[:nev].copy()
-    spec = B.spectrum_check(lam, N, nev)
-    meta = {"workload": workload, "N": N, "cplx": bool(cplx), "nev": nev, "nex": nex,
+    spec = None if pseudo else B.spectrum_check(lam, N, nev)
+    meta = {"workload": workload, "pseudo": pseudo, "N": N, "cplx": bool(cplx), "nev": nev, "nex": nex,
             "iterations": st["iterations"], "filtered_vecs": st["filtered_vecs"], "locked": st["locked"],
             "solve_seconds": st["t_all"], "wall_seconds": wall, "phases": {k: st[k] for k in B.PHASES},
             "filter_seconds_device": st["filter_ms_device"] * 1e-3,
@@ -48,6 +61,8 @@ def record_tape(ctx, workload, n_override=0, log=None):
             "residuals_rechecked_on_the_tolerance": int(s.get("resd_rechecked"))}
     s.close()
     dH.free()
+    if grid is not None:
+        grid.close()
     return tape, meta
 
 
@@ -76,10 +91,16 @@ def replay_rank(ctx, tape, meta, nprow, npcol, rank=0, block_cyclic=None, oplog=
         grid.set_loopback_model(model.get("busbw_GBps", 0.0), model.get("latency_us", 0.0), model.get("touch", False),
                                 model.get("workgroups", 0))
     rl, cl = cd.Layout(N, nb, nprow), cd.Layout(N, nb, npcol)
-    dH = cd.gen_clement_local(ctx, N, cplx, rl, cl, grid.myrow, grid.mycol, scale=B.MATRIX_SCALE / N, perturb=B.MATRIX_PERTURB)
-    ctx.sync()
-    s = cd.DistSolver(ctx, grid, dH, N, nev, nex, cplx, nb, nb)
-    s.set(device_rng=1)
+    if meta.get("pseudo"):
+        dH = cd.gen_bse_local(ctx, N, cplx, rl, cl, grid.myrow, grid.mycol, **B.BSE_MATRIX)
+        ctx.sync()
+        s = cd.DistPseudoSolver(ctx, grid, dH, N, nev, nex, cplx, nb, nb)
+        s.set(device_rng=1, numlanczos=10, lanczositer=50)
+    else:
+        dH = cd.gen_clement_local(ctx, N, cplx, rl, cl, grid.myrow, grid.mycol, scale=B.MATRIX_SCALE / N, perturb=B.MATRIX_PERTURB)
+        ctx.sync()
+        s = cd.DistSolver(ctx, grid, dH, N, nev, nex, cplx, nb, nb)
+        s.set(device_rng=1)
     if settings and "pipeline" in settings:
         s.set(pipeline=settings["pipeline"])
     if settings and settings.get("panel_cols"):
@@ -144,6 +165,7 @@ def replay_rank(ctx, tape, meta, nprow, npcol, rank=0, block_cyclic=None, oplog=
            "iterations": st["iterations"], "filtered_vecs": st["filtered_vecs"], "locked": st["locked"],
            "call_sequence_equals_recording": bool(ok), "qr_variant_mismatches": int(s.get("tape_qr_mismatches")),
            "qr_shifted_refactorisations_on_replayed_numbers": int(s.get("tape_qr_retries")),
+           "projected_matrices_replaced_by_the_identity": int(s.get("tape_tolerated")),
            "residuals_rechecked": int(s.get("resd_rechecked")),
            "waits_on_communication_streams": int(waits), "exposed_ms_of_those_waits_with_nothing_on_the_wire": exposed_ms,
            "gemm_books": books, "per_iteration": per_iter,

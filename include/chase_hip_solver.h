@@ -69,8 +69,9 @@ int chase_hip_solver_set_iteration_hook(chase_hip_solver* s, chase_hip_iteration
  * mode 2: the next solves replay a loaded tape - the Impl executes every operator at ITS shapes, the driver is shown the
  * recorded numbers and so issues exactly the recorded call sequence; 0: off.  With a loopback grid
  * (chase_hip_grid_create_loopback) this measures ONE rank of a multi-GPU solve on a one-GPU box (bench.py --replay-rank).
- * get keys after a replay: tape_qr_mismatches (QR calls that took another variant than recorded), tape_position, tape_size.
- * Hermitian solves only.  The data pointer stays valid until the next solve / load on this solver. */
+ * get keys after a replay: tape_qr_mismatches (QR calls that took another variant than recorded), tape_position, tape_size,
+ * tape_tolerated (pseudo-Hermitian replay: projected matrices of partial sums that did not factorise, run on the identity).
+ * Both drivers (chase::Solve and, on the grid Impl, chase::Solve_pseudo).  The data pointer stays valid until the next solve / load on this solver. */
 int chase_hip_solver_tape_mode(chase_hip_solver* s, int mode);
 int chase_hip_solver_tape_data(chase_hip_solver* s, const double** data, size_t* count);
 int chase_hip_solver_tape_load(chase_hip_solver* s, const double* data, size_t count);
