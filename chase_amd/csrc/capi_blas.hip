@@ -32,7 +32,6 @@ using namespace chase_hip;
 
 namespace {
 constexpr int NB = 64;
-constexpr size_t WS_DEFAULT = (size_t)640 << 20;
 
 inline int ept_of(int cplx) { return cplx ? 2 : 1; }
 

@@ -80,15 +80,15 @@ int chase_hip_ctx_create(chase_hip_ctx** out, int device, void* stream)
 int chase_hip_ctx_destroy(chase_hip_ctx* c)
 {
     if (!c) return 0;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    if (c->ws) hipFree(c->ws);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->ws) (void)hipFree(c->ws);
     for (int i = 0; i < chase_hip_ctx::NBUF; ++i)
-        if (c->bufs[i]) hipFree(c->bufs[i]);
-    if (c->hstage) hipHostFree(c->hstage);
-    hipEventDestroy(c->ev0);
-    hipEventDestroy(c->ev1);
-    if (c->own_stream) hipStreamDestroy(c->stream);
+        if (c->bufs[i]) (void)hipFree(c->bufs[i]);
+    if (c->hstage) (void)hipHostFree(c->hstage);
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
 }

@@ -233,21 +233,21 @@ int chase_hip_grid_destroy(chase_hip_grid* g)
     if (!g) return 0;
     if (g->ctx) hipSetDevice(g->ctx->device);
     for (int i = 0; i < 2; ++i)
-        if (g->comm_stream[i]) hipStreamSynchronize(g->comm_stream[i]);
+        if (g->comm_stream[i]) (void)hipStreamSynchronize(g->comm_stream[i]);
     for (int i = 0; i < 2; ++i)
-        if (g->comm[i]) ncclCommDestroy(g->comm[i]);
-    if (g->scal_dev) hipFree(g->scal_dev);
-    if (g->fab_ready) hipEventDestroy(g->fab_ready);
-    if (g->fab_done) hipEventDestroy(g->fab_done);
+        if (g->comm[i]) (void)ncclCommDestroy(g->comm[i]);
+    if (g->scal_dev) (void)hipFree(g->scal_dev);
+    if (g->fab_ready) (void)hipEventDestroy(g->fab_ready);
+    if (g->fab_done) (void)hipEventDestroy(g->fab_done);
     for (int i = 0; i < 2; ++i)
         for (hipEvent_t e : g->slots[i])
-            if (e) hipEventDestroy(e);
-    for (auto& pr : g->ev_pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-    for (hipEvent_t e : g->ev_pool) hipEventDestroy(e);
-    if (g->ev_compute) hipEventDestroy(g->ev_compute);
+            if (e) (void)hipEventDestroy(e);
+    for (auto& pr : g->ev_pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (hipEvent_t e : g->ev_pool) (void)hipEventDestroy(e);
+    if (g->ev_compute) (void)hipEventDestroy(g->ev_compute);
     for (int i = 0; i < 2; ++i) {
-        if (g->ev_comm[i]) hipEventDestroy(g->ev_comm[i]);
-        if (g->comm_stream[i]) hipStreamDestroy(g->comm_stream[i]);
+        if (g->ev_comm[i]) (void)hipEventDestroy(g->ev_comm[i]);
+        if (g->comm_stream[i]) (void)hipStreamDestroy(g->comm_stream[i]);
     }
     delete g;
     return 0;

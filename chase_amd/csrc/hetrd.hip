@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(const double* __restrict_
     const int i = blockIdx.x * TRB + threadIdx.x;
     const int j0 = blockIdx.y * TCW;
     const int jn = min(TCW, m - j0);
-    if (threadIdx.x < jn * E) vs[threadIdx.x] = vbuf[(long)j0 * E + threadIdx.x];
+    if ((int)threadIdx.x < jn * E) vs[threadIdx.x] = vbuf[(long)j0 * E + threadIdx.x];
     __syncthreads();
     if (i >= m) return;
     const double* a = A + ((long)(k + 1 + j0) * lda + (k + 1) + i) * E;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void trd_her2_kernel(double* __restrict__ A, l
     const double alr = -0.5 * (tr * qr - ti * qi), ali = -0.5 * (tr * qi + ti * qr);
     const int j0 = blockIdx.y * UCW;
     const int jn = min(UCW, m - j0);
-    if (threadIdx.x < jn) {
+    if ((int)threadIdx.x < jn) {
         const int j = j0 + threadIdx.x;
         const double vr = vbuf[(long)j * E], vi = CPLX ? vbuf[(long)j * E + 1] : 0.0;
         const double pr = pbuf[(long)j * E], pi = CPLX ? pbuf[(long)j * E + 1] : 0.0;
@@ -595,6 +595,7 @@ extern "C" int chase_hip_heevd_gpu(chase_hip_ctx* c, int cplx_, int n, void* A_,
         return 0;
     };
     rc = body();
-    hipStreamSynchronize(st);
+    const hipError_t es = hipStreamSynchronize(st);        // a faulting kernel must not pass for success
+    if (rc == 0 && es != hipSuccess) return hip_fail(es, "heevd: hipStreamSynchronize");
     return rc;
 }

@@ -434,7 +434,8 @@ int hh_apply_q_left(chase_hip_ctx* c, bool cplx, const double* Vstore, long ldv,
         return 0;
     };
     const int rc = body();
-    hipStreamSynchronize(st);
+    const hipError_t es = hipStreamSynchronize(st);        // a faulting kernel must not pass for success
+    if (rc == 0 && es != hipSuccess) return hip_fail(es, "houseqr: hipStreamSynchronize");
     return rc;
 }
 } // namespace chase_hip
@@ -509,8 +510,9 @@ extern "C" int chase_hip_houseqr(chase_hip_ctx* c, int cplx_, int m, int n, void
         return 0;
     };
     rc = body();
-    hipStreamSynchronize(st);
-    hipFree(blk);
+    const hipError_t es = hipStreamSynchronize(st);        // a faulting kernel must not pass for success
+    (void)hipFree(blk);
+    if (rc == 0 && es != hipSuccess) return hip_fail(es, "houseqr: hipStreamSynchronize");
     return rc;
 }
 
@@ -601,7 +603,8 @@ extern "C" int chase_hip_houseqr_dist(chase_hip_ctx* c, chase_hip_grid* grid, in
         return 0;
     };
     const int rc = body();
-    hipStreamSynchronize(st);
-    hipFree(blk);
+    const hipError_t es = hipStreamSynchronize(st);        // a faulting kernel must not pass for success
+    (void)hipFree(blk);
+    if (rc == 0 && es != hipSuccess) return hip_fail(es, "houseqr: hipStreamSynchronize");
     return rc;
 }

@@ -415,8 +415,9 @@ int stedc_gpu(chase_hip_ctx* c, int n, const double* d_in, const double* e_in, d
         DCHK(hipStreamSynchronize(st));
         return 0;
     };
-    const int rc = body();
-    hipStreamSynchronize(st);
+    int rc = body();
+    const hipError_t es = hipStreamSynchronize(st);        // a faulting kernel must not pass for success
+    if (rc == 0 && es != hipSuccess) rc = hip_fail(es, "stedc_gpu: hipStreamSynchronize");
     if (dbg && rc == 0)
         fprintf(stderr, "stedc_gpu n=%d: %d leaves, %.2f ms\n", n, nleaf,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());

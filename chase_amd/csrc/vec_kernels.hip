@@ -40,7 +40,7 @@ int chase_hip_ctx::ensure_ws(size_t bytes)
 {
     if (ws_bytes >= bytes) return 0;
     (void)hipSetDevice(device);
-    if (ws) { hipStreamSynchronize(stream); hipFree(ws); ws = nullptr; ws_bytes = 0; }
+    if (ws) { (void)hipStreamSynchronize(stream); (void)hipFree(ws); ws = nullptr; ws_bytes = 0; }
     hipError_t e = hipMalloc(&ws, bytes);
     if (e != hipSuccess) return chase_hip::set_error(CHASE_HIP_ENOMEM, "workspace allocation failed");
     ws_bytes = bytes;
@@ -51,7 +51,7 @@ int chase_hip_ctx::ensure_buf(int idx, size_t bytes)
 {
     if (buf_bytes[idx] >= bytes) return 0;
     (void)hipSetDevice(device);
-    if (bufs[idx]) { hipStreamSynchronize(stream); hipFree(bufs[idx]); bufs[idx] = nullptr; buf_bytes[idx] = 0; }
+    if (bufs[idx]) { (void)hipStreamSynchronize(stream); (void)hipFree(bufs[idx]); bufs[idx] = nullptr; buf_bytes[idx] = 0; }
     hipError_t e = hipMalloc(&bufs[idx], bytes);
     if (e != hipSuccess) return chase_hip::set_error(CHASE_HIP_ENOMEM, "scratch allocation failed");
     buf_bytes[idx] = bytes;
@@ -62,7 +62,7 @@ int chase_hip_ctx::ensure_hstage(size_t bytes)
 {
     if (hstage_bytes >= bytes) return 0;
     (void)hipSetDevice(device);
-    if (hstage) { hipStreamSynchronize(stream); hipHostFree(hstage); hstage = nullptr; hstage_bytes = 0; }
+    if (hstage) { (void)hipStreamSynchronize(stream); (void)hipHostFree(hstage); hstage = nullptr; hstage_bytes = 0; }
     hipError_t e = hipHostMalloc(&hstage, bytes, hipHostMallocDefault);
     if (e != hipSuccess) return chase_hip::set_error(CHASE_HIP_ENOMEM, "pinned staging allocation failed");
     hstage_bytes = bytes;
