@@ -42,3 +42,20 @@ def test_replay_issues_the_recorded_call_sequence_on_another_kernel(harness, N, 
     assert calls["C"] != calls["A"]
     # a tape that ends early stops the replay instead of letting it run on
     assert next(l for l in out if l.startswith("truncated")).startswith("truncated tape:")
+
+
+def test_replay_of_the_pseudo_hermitian_driver(harness):
+    """chase::Solve_pseudo through the tape (round 5: bench.py --replay-rank on the pseudo-Hermitian workload): a scripted kernel
+    A is recorded, another script B replayed - B's driver issues A's calls (H^2 filter steps, K-conjugations, the +- Ritz pairs of
+    rayleighRitz_v2 taken from the tape: 2 * block values per RR frame)"""
+    out = subprocess.run([harness, "pseudo"], check=True, capture_output=True, text=True, timeout=600).stdout.splitlines()
+    calls = {k: [l[2:] for l in out if l.startswith(k + " ") and not l.split()[1] in ("iterations",)] for k in "ABC"}
+    head = {k: next(l for l in out if l.startswith(k + " iterations")).split() for k in "ABC"}
+    assert len(calls["A"]) > 50 and any(c.startswith("HEMM_H2") for c in calls["A"]) and any(c.startswith("ApplyKconjugate") for c in calls["A"])
+    assert calls["B"] == calls["A"]
+    assert head["B"][2] == head["A"][2] and head["B"][4] == head["A"][4] and head["B"][6] == head["A"][6]
+    assert int(head["B"][8]) == int(next(l for l in out if l.startswith("tape_size")).split()[1])
+    ritz = [l.split()[1:] for l in out if l.startswith("ritz ")]
+    assert len(ritz) == 16 and all(a == b for a, b in ritz)
+    assert calls["C"] != calls["A"]
+    assert next(l for l in out if l.startswith("truncated")).startswith("truncated tape:")
