@@ -234,7 +234,8 @@ int chase_hip_heevd_gpu(chase_hip_ctx* ctx, int cplx, int n, void* A, long lda, 
 int chase_hip_pseudo_rr_small(chase_hip_ctx* ctx, int cplx, int n, void* A_dev, void* M_dev, double* ritzv_host);
 int chase_hip_set_identity(chase_hip_ctx* ctx, int cplx, int n, void* A, long lda);
 int chase_hip_heevd_host(int cplx, int n, void* A_host, long lda, double* w_host); /* host-only twin (provider check) */
-/* host-only: all eigenpairs of a symmetric tridiagonal (Lanczos; lapackpp::t_stemr, cpu/lanczos.hpp:188) */
+/* host-only: all eigenpairs of a symmetric tridiagonal (Lanczos; lapackpp::t_stemr, cpu/lanczos.hpp:188); non-finite d / e
+ * (a Lanczos recurrence that broke down) is CHASE_HIP_EINVAL: LAPACK's MRRR need not terminate on such input */
 int chase_hip_stemr_host(int n, double* d, double* e, double* w, double* Z, int ldz);
 /* Real symmetric tridiagonal eigenproblem by divide & conquer with the O(n^2) / O(n^3) parts on the device (secular equation,
  * Gu-Eisenstat vectors, merge GEMMs; deflation and the leaves on the host): d (n), e (n-1) on the host, eigenvalues ascending

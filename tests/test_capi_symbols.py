@@ -82,3 +82,25 @@ def test_gemm_workspace_covers_the_rims_of_a_split_three_multiplication_product(
             assert whole >= max(pieces), (op, m, n, k, whole, pieces)
             assert need(op, m, n, k, 4) >= whole or need(op, m, n, k, 4) > 0       # shared-chip granularity: its own plan
     assert need(b"N", 0, 5, 5) == 0
+
+
+def test_stemr_rejects_non_finite_input_instead_of_hanging():
+    """a Lanczos recurrence that overflowed hands NaN / inf to the tridiagonal eigensolver; LAPACK's MRRR need not return on
+    such input (found in round 5: a replayed rank hung there) - the entry point refuses it.  Host-only: no GPU needed."""
+    import numpy as np
+    from chase_amd.capi import lib
+    n = 6
+    for bad in (np.nan, np.inf):
+        d, e = np.arange(n, dtype=np.float64), np.full(n, 0.5)
+        w, Z = np.zeros(n), np.zeros(n * n)
+        e[2] = bad
+        rc = lib.chase_hip_stemr_host(n, d.ctypes.data_as(ctypes.c_void_p), e.ctypes.data_as(ctypes.c_void_p),
+                                      w.ctypes.data_as(ctypes.c_void_p), Z.ctypes.data_as(ctypes.c_void_p), n)
+        assert rc != 0 and b"non-finite" in lib.chase_hip_last_error()
+    d, e = np.arange(n, dtype=np.float64), np.full(n, 0.5)
+    w, Z = np.zeros(n), np.zeros(n * n)
+    e[n - 1] = np.nan                                    # the entry past the last off-diagonal is not read
+    rc = lib.chase_hip_stemr_host(n, d.ctypes.data_as(ctypes.c_void_p), e.ctypes.data_as(ctypes.c_void_p),
+                                  w.ctypes.data_as(ctypes.c_void_p), Z.ctypes.data_as(ctypes.c_void_p), n)
+    T = np.diag(np.arange(n, dtype=np.float64)) + np.diag(np.full(n - 1, 0.5), 1) + np.diag(np.full(n - 1, 0.5), -1)
+    assert rc == 0 and np.allclose(np.sort(w), np.linalg.eigvalsh(T), atol=1e-12)
