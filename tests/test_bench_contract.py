@@ -49,6 +49,22 @@ def test_step_timer_times_exactly_k_iterations(steps, warmup):
     assert timer.filtered_timed == sum(100 - (i % s.iters) for i in range(warmup, total))
 
 
+def test_a_solves_seconds_exclude_what_its_hooks_waited_for():
+    """The join of the CPU-baseline child (before_timed) and the brackets of the timed region run inside a solve's iteration
+    hooks: their seconds are not the solver's (round 5: the default short run reported 18.7 s for a 2.5 s config-2 solve)."""
+    import time
+    s = FakeSolver()
+    timer = B.StepTimer(6, 3, lambda: None, lambda: None, lambda: dict(s.counters), before_timed=lambda: time.sleep(0.25))
+    complete, _ = B.run_timed_solves(s, timer, s.nev, lambda: ("lam", "res"))
+    assert len(complete) == 1
+    assert complete[0]["t_all_with_bench_waits"] == 1.0 and 0.70 <= complete[0]["t_all"] <= 0.7501
+    # a solve whose hooks waited for nothing keeps its seconds
+    s2 = FakeSolver()
+    t2 = B.StepTimer(9, 9, lambda: None, lambda: None, lambda: dict(s2.counters))
+    c2, _ = B.run_timed_solves(s2, t2, s2.nev, lambda: ("lam", "res"))
+    assert c2[-1]["t_all"] == pytest.approx(1.0, abs=1e-3)
+
+
 def test_roofline_fraction_is_executed_and_bounded():
     r = B.roofline_object(model_flops=4.0e15, exec_flops=3.0e15, filt_s=50.0, calls=100, world=1)
     assert r["frac"] == pytest.approx(60.0 / B.FP64_MFMA_PEAK_TFLOPS) and r["frac"] <= 1.0
