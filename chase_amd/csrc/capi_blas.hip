@@ -666,18 +666,18 @@ int chase_hip_pseudo_rr_small(chase_hip_ctx* c, int cplx, int n, void* A_dev, vo
     // one line for the whole dense core: its inner sequence ends early when A does not factorise (data-dependent)
     struct Mute { chase_hip_ctx* c; Mute(chase_hip_ctx* x) : c(x) { ++c->oplog_mute; } ~Mute() { --c->oplog_mute; } } mute(c);
     const size_t bytes = (size_t)n * n * sizeof(double) * ept_of(cplx);
-    RCCHK(c->ensure_hstage(2 * bytes));
-    double* hA = (double*)c->hstage;
-    double* hM = (double*)((char*)c->hstage + bytes);
-    HIPCHK(hipMemcpyAsync(hA, A_dev, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(hM, M_dev, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
     // large cores (config 5: 2 (nev + nex) = 640): everything on the device like the reference's GPU path
     // (linalg/internal/cuda/rayleighRitz.hpp:511-600: cusolver potrf, cublas trsm, cusolver heevd) - see pseudo_rr_device;
     // CHASE_HIP_PSEUDO_RR_DEVICE=0 keeps round 3's split (potrf and the three trsm on the host, heevd on the device)
     static const int gpu_min = [] { const char* e = getenv("CHASE_HIP_HEEVD_GPU_MIN"); return e ? atoi(e) : 384; }();
     static const bool dev_core = [] { const char* e = getenv("CHASE_HIP_PSEUDO_RR_DEVICE"); return e ? atoi(e) != 0 : true; }();
     if (gpu_min > 0 && n >= gpu_min && dev_core) return pseudo_rr_device(c, cplx, n, (double*)A_dev, (double*)M_dev, ritzv_host);
+    RCCHK(c->ensure_hstage(2 * bytes));                      // the host paths work on copies of A and M
+    double* hA = (double*)c->hstage;
+    double* hM = (double*)((char*)c->hstage + bytes);
+    HIPCHK(hipMemcpyAsync(hA, A_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(hM, M_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     if (gpu_min > 0 && n >= gpu_min) {
         int rc = host_pseudo_rr_pre(cplx != 0, n, hA, hM);
         if (rc) return rc;
