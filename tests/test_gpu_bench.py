@@ -42,6 +42,7 @@ def test_single_gpu_line_keeps_the_contract():
     check_common(d, 1, 9, 0)
     assert d["iterations_per_solve"] == 9 and d["filtered_vecs_per_solve"] == 101708        # the oracle's counts for config 2
     assert d["roofline"]["frac"] > 0.5                                                       # a fallback path would not get here
+    assert 1.0 < d["solve_seconds"] < 6.0 and d["eigenpairs_per_sec"] > 80                   # the solve's own seconds (2.5 s), no bench waits in them
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "extrapolated" in c["sample"]
     for probe in ("roofline_4m", "roofline_3m_fullwidth"):
