@@ -194,7 +194,7 @@ def run_rank(args, comm, ctx, grid, mode):
     # first contact with the hardware: the knobs of the panel pipeline are measured on identical full-width filter steps and
     # the best setting is locked BEFORE the first solve (chase_amd/autotune.py); untimed, a few seconds
     tuned = None
-    if (world > 1 and not pseudo and not getattr(args, "no_autotune", False)
+    if (world > 1 and not getattr(args, "no_autotune", False)
             and (is_rccl or os.environ.get("CHASE_HIP_AUTOTUNE_HOST") == "1")):
         from .autotune import first_contact
         tuned = first_contact(s, ctx, grid, comm, nevex, budget=int(os.environ.get("CHASE_HIP_AUTOTUNE_TRIALS", "5")),

@@ -102,6 +102,12 @@ public:
             auto need = [&](std::size_t rows) { const std::size_t rt = std::max<std::size_t>(1, (rows + 127) / 128); return ((slots + rt - 1) / rt) * bn; };
             const std::size_t w = std::max(need(m_), need(n_));
             panel_ = std::min<std::size_t>(2048, std::max<std::size_t>(256, (w + 255) / 256 * 256));
+            // ... but a product must still consist of SEVERAL panels, or nothing of its all-reduce can hide: at most 1 / 2.5 of
+            // the filter's block width (nev + nex columns), not below 128.  Found with the single-rank replay of config 5 on
+            // 4 x 2 (320 columns, m_loc = 8192: the rule above gives one 512-column panel): against collectives modelled at
+            // 50 GB/s T_rank 3.82 s with that panel, 2.84 s with 128 (profiles/r05_replay_cfg5_4x2_panels_modelled.json)
+            const std::size_t cap = std::max<std::size_t>(128, ((nevex_ * 2 + 4) / 5 + bn - 1) / bn * bn);
+            panel_ = std::min(panel_, cap);
         }
         build_diag_lists();
         build_redistribution();

@@ -292,7 +292,11 @@ def scenario_knob_switching(ctx, grid, comm, N, nev, nex, cplx, mb, deg):
     s = cd.DistSolver(ctx, grid, dH, N, nev, nex, cplx, mb, mb)
     s.set(deg=deg)
     base = A.current_setting(s, grid)
-    assert base["comm_streams"] == 1 and base["panel_rounds"] == 4 and base["panel_cols"] >= 256
+    # defaults: one communication stream, K pieces, a panel that fills the chip once but at most 1 / 2.5 of the block width
+    # (a product must consist of several panels for any of its all-reduce to hide), never below 128
+    bn = 64 if cplx else 128
+    cap = max(128, -(-(-(-(nev + nex) * 2 // 5)) // bn) * bn)          # ceil(ceil(2 (nev + nex) / 5) / bn) * bn
+    assert base["comm_streams"] == 1 and base["panel_rounds"] == 4 and 128 <= base["panel_cols"] <= max(cap, 128)
     st0 = s.solve()
     lam0 = s.ritzv[:nev].copy()
     cycle = [{"panel_cols": 64, "panel_rounds": 0, "comm_streams": 1}, {"panel_cols": 512, "panel_rounds": 4, "comm_streams": 2},
