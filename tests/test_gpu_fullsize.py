@@ -99,7 +99,8 @@ def test_cfg5_shape_at_full_size_against_the_oracle(fixture):
     print(json.dumps(rec), flush=True)
     assert rec["locked"] >= rec["nev"]
     assert rec["iterations"] == gold["iterations"], (rec["iterations"], gold["iterations"])
-    # full size, observed: 10 iterations on both sides, 153 772 against the oracle's 153 004 vectors (+0.50 %), eigenvalue sum equal
+    # full size, observed: 10 iterations on both sides, 153 448 - 153 772 (depending on the panel decomposition: +0.3 .. +0.5 %)
+    # against the oracle's 153 004 vectors, eigenvalue sum equal
     # to all 16 digits; N = 1024: 6 / 12 844 on both sides.  SURVEY Appendix A asks for +-5 % here; the bar is 1 %.
     assert abs(rec["filtered_vecs"] - gold["filtered_vecs"]) <= 0.01 * gold["filtered_vecs"], (rec["filtered_vecs"], gold["filtered_vecs"])
     assert max(abs(a - b) for a, b in zip(rec["lambda_first"] + rec["lambda_last"], gold["lambda_first"] + gold["lambda_last"])) < 1e-8
