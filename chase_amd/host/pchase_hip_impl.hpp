@@ -100,7 +100,9 @@ public:
         {
             const std::size_t bn = CP ? 64 : 128, slots = 512;
             auto need = [&](std::size_t rows) { const std::size_t rt = std::max<std::size_t>(1, (rows + 127) / 128); return ((slots + rt - 1) / rt) * bn; };
-            const std::size_t w = std::max(need(m_), need(n_));
+            // (from the LARGEST local block of the layout, not from mine: every rank must arrive at the same panel grid - the
+            // panels are what the all-reduces carry - and local row counts differ by one block remainder between ranks)
+            const std::size_t w = std::max(need((std::size_t)Rr_.count(0)), need((std::size_t)Cc_.count(0)));
             panel_ = std::min<std::size_t>(2048, std::max<std::size_t>(256, (w + 255) / 256 * 256));
             // ... but a product must still consist of SEVERAL panels, or nothing of its all-reduce can hide: at most 1 / 2.5 of
             // the filter's block width (nev + nex columns), not below 128.  Found with the single-rank replay of config 5 on

@@ -38,6 +38,30 @@ def test_operators_vs_oracle(nranks, typ, mb):
     run(nranks, S.scenario_ops, typ == "z", mb)
 
 
+def _panel_of_my_rank(ctx, grid, comm, N, nev, nex, out):
+    import numpy as np
+    from chase_amd import dist as cd
+    rl, cl = cd.Layout(N, 0, grid.nprow), cd.Layout(N, 0, grid.npcol)
+    m, n = rl.count(grid.myrow), cl.count(grid.mycol)
+    dH = ctx.empty((m, n), np.complex128)                      # never read: only the object is built
+    s = cd.DistSolver(ctx, grid, dH, N, nev, nex, True, 0, 0)
+    out[comm.rank] = (m, n, int(s.get("panel_cols")))
+    comm.barrier()
+    s.close()
+    dH.free()
+
+
+def test_every_rank_derives_the_same_panel_grid():
+    """The panels are what the pipelined all-reduces carry: every rank must arrive at the same width.  N = 32513 on two grid
+    rows gives local blocks of 16257 and 16256 rows - 128 and 127 row tiles, for which "a panel fills the chip once" means 256
+    and 320 -> 512 columns when taken from the rank's OWN block (rounds 2-4 did: a latent mismatch for such shapes); the width
+    comes from the layout's largest block now."""
+    out = {}
+    run_ranks(2, 1, _panel_of_my_rank, 32513, 1200, 400, out)
+    assert out[0][0] == 16257 and out[1][0] == 16256
+    assert out[0][2] == out[1][2] == 256, out
+
+
 @pytest.mark.parametrize("nranks,cplx,mb", [(4, True, 16), (8, False, 32)])
 def test_pipeline_knobs_switched_between_iterations(nranks, cplx, mb):
     run(nranks, S.scenario_knob_switching, 640, 40, 24, cplx, mb, 20)
