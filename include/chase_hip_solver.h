@@ -52,7 +52,12 @@ int chase_hip_psolver_set_pipeline(chase_hip_solver* s, int on); /* 0: no comput
 int chase_hip_solver_destroy(chase_hip_solver* s);
 /* keys: tol deg maxdeg degextra maxiter lanczositer numlanczos opt approx cholqr decayingrate clusteraware upperbscale
  * (ChaseConfig setters, algorithm/configuration.hpp:197-462); get additionally: locked qr_variant filter_ms hemm_calls
- * hemm_reused_vecs, and iterations / filtered_vecs of the last solve */
+ * hemm_reused_vecs resd_rechecked, and iterations / filtered_vecs of the last solve.
+ * Grid Impls, run-time knobs of the panel-pipelined HEMM (set and get; COLLECTIVE: the same value on every rank at the same
+ * point): panel_cols (a multiple of 64 in [64, 4096]; default: the width whose GEMM fills the chip once with whole tiles, computed
+ * from the layout's largest local block, but at most 1 / 2.5 of nev + nex and not below 128 - a product must consist of several
+ * panels for any of its all-reduce to hide), panel_rounds (K pieces of a panel product that shares the chip with a collective,
+ * 0..16, default 4 = CHASE_HIP_PANEL_ROUNDS), pipeline (0: every all-reduce waited for where it is issued). */
 int chase_hip_solver_set(chase_hip_solver* s, const char* key, double value);
 int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* value);
 int chase_hip_solver_solve(chase_hip_solver* s, int record_trace);
