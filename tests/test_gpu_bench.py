@@ -99,6 +99,26 @@ def test_multi_rank_bench_with_real_rccl_collectives(ngpus, grid):
     assert d["scaling_valid"] is False          # RCCL over fake hosts' sockets: a rehearsal, never a scaling number
 
 
+def test_pseudo_hermitian_workload_over_real_rccl_with_self_tuning():
+    """BASELINE configs[4]'s path (Solve_pseudo on the grid Impl, H^2 filter) through `bench.py --gpus 4` over REAL RCCL
+    communicators (fake hosts: socket transport, four rank processes on this box's GPU) at N = 4096: the first-contact self-tuning
+    runs its trial steps with HEMM_H2 (round 5: it used to be skipped for this workload, whose default panel then hid nothing of
+    an all-reduce), the solve converges, the line carries the table."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "cfg5", "--n", "4096", "--steps", "6",
+                        "--warmup", "0", "--no-cpu-baseline", "--no-probe"], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CHASE_BENCH_FAKE_HOSTS="1", CHASE_HIP_AUTOTUNE_TRIALS="3"))
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 4 and d["config"]["grid"] == "2x2" and d["config"]["transport"] == "rccl"
+    assert "pseudo-Hermitian" in d["config"]["workload"]
+    assert d["converged"] is True and 0.0 < d["max_resid_recomputed"] < 1e-8
+    a = d["autotune"]
+    assert a["base"]["panel_cols"] == 128 and a["base"]["comm_streams"] == 1            # 320 filter columns: capped at 1 / 2.5 of them
+    assert len(a["trials"]) == 3 and [t["setting"]["panel_cols"] for t in a["trials"]] == [128, 256, 512]
+    assert sum(t["kept"] for t in a["trials"]) == 1 and all(t["seconds"] > 0 for t in a["trials"])
+    assert d["scaling_valid"] is False
+
+
 def test_config3_at_full_size_over_real_rccl_communicators():
     """BASELINE configs[2] exactly as the 4-GPU job runs it (N = 32768 real symmetric, nev = 1024, nex = 256, 2 x 2 block
     distribution, RCCL row / column all-reduces) - with the four rank processes sharing this box's one GPU and RCCL on its socket
