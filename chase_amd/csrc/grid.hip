@@ -79,7 +79,7 @@ static int grid_common(chase_hip_grid* g, chase_hip_ctx* ctx, int nprow, int npc
     }
     HIPCHK(hipEventCreateWithFlags(&g->ev_compute, hipEventDisableTiming));
     if (const char* e = getenv("CHASE_HIP_COMM_STREAMS")) g->nstreams = atoi(e) == 2 ? 2 : 1;
-    HIPCHK(hipMalloc((void**)&g->scal_dev, 64));
+    HIPCHK(hipMalloc((void**)&g->scal_dev, 256));
     return 0;
 }
 
@@ -415,6 +415,39 @@ int chase_hip_grid_agree_max(chase_hip_grid* g, int* value)
         for (int i = 0; i < sz; ++i) cur = std::max(cur, (int)std::lround(v[i]));
     }
     *value = cur;
+    return 0;
+}
+
+/* Do all ranks of the grid hold the same 64-bit value (a content hash of something that must be replicated bit for bit)?
+ * *all_equal = 1 / 0, identical on every rank.  Same mechanism as agree_max: every member writes (low half, high half,
+ * "my row already disagrees") into its own slots of a zeroed vector, SUM all-reduce inside the row groups, then inside the
+ * column groups on the row's verdict - two 24-double collectives. */
+int chase_hip_grid_agree_equal(chase_hip_grid* g, unsigned long long value, int* all_equal)
+{
+    if (!g || !all_equal) return set_error(CHASE_HIP_EINVAL, "agree_equal: NULL argument");
+    *all_equal = 1;
+    if (g->nprow * g->npcol == 1 && !g->force) return 0;
+    if (g->ctx->oplog_on) g->ctx->oplog_add("agree_equal", 0, 0, 0, 0);
+    if (g->loopback) return 0;
+    chase_hip_ctx* c = g->ctx;
+    struct Mute { chase_hip_ctx* c; Mute(chase_hip_ctx* x) : c(x) { ++c->oplog_mute; } ~Mute() { --c->oplog_mute; } } mute(c);
+    int bad = 0;
+    for (int grp : {CHASE_HIP_ROW, CHASE_HIP_COL}) {
+        if (!g->active(grp)) continue;
+        const int sz = g->group_size(grp), me = g->group_rank(grp);
+        if (sz > 8) return set_error(CHASE_HIP_EINVAL, "agree_equal: group larger than the scratch (8)");
+        double v[24];
+        for (double& x : v) x = 0.0;
+        v[me] = (double)(value & 0xffffffffull); v[8 + me] = (double)(value >> 32); v[16 + me] = (double)bad;
+        HIPCHK(hipMemcpyAsync(g->scal_dev, v, sizeof v, hipMemcpyHostToDevice, c->stream));
+        int rc = chase_hip_grid_allreduce(g, grp, g->scal_dev, 24, 0);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(v, g->scal_dev, sizeof v, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < sz; ++i)
+            if (v[i] != v[0] || v[8 + i] != v[8] || v[16 + i] != 0.0) bad = 1;
+    }
+    *all_equal = !bad;
     return 0;
 }
 

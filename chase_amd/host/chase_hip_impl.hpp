@@ -24,6 +24,7 @@
 #include "../../include/chase_hip.h"
 #include "impl_extras.hpp"
 #include "interface.hpp"
+#include "output_override.hpp"
 #include "roctx.hpp"
 
 namespace chase_amd {
@@ -39,7 +40,7 @@ struct HipStatusError : std::runtime_error {
 inline void hip_ok(int rc, const char* where) { if (rc < 0) throw HipStatusError(rc, where); }
 
 template <class T, class BaseT = ChaseBase<T>, class ConfigT = ChaseConfig<T>>
-class ChaseHip : public BaseT, public HipImplExtras {
+class ChaseHip : public WithOutput<BaseT>, public HipImplExtras {
 public:
     using R = Base<T>;
     static constexpr int CP = is_cplx<T>::value ? 1 : 0;

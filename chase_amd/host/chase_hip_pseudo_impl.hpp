@@ -21,12 +21,13 @@
 #include "../../include/chase_hip.h"
 #include "chase_hip_impl.hpp"
 #include "interface.hpp"
+#include "output_override.hpp"
 #include "roctx.hpp"
 
 namespace chase_amd {
 
 template <class T, class BaseT = ChaseBase<T>, class ConfigT = ChaseConfig<T>>
-class ChaseHipPseudo : public BaseT, public HipImplExtras {
+class ChaseHipPseudo : public WithOutput<BaseT>, public HipImplExtras {
 public:
     using R = Base<T>;
     static constexpr int CP = is_cplx<T>::value ? 1 : 0;

@@ -37,13 +37,14 @@
 #include "../../include/chase_hip_grid.h"
 #include "chase_hip_impl.hpp"
 #include "interface.hpp"
+#include "output_override.hpp"
 #include "panel_pipeline.hpp"
 #include "roctx.hpp"
 
 namespace chase_amd {
 
 template <class T, class BaseT = ChaseBase<T>, class ConfigT = ChaseConfig<T>>
-class pChaseHip : public BaseT, public HipImplExtras {
+class pChaseHip : public WithOutput<BaseT>, public HipImplExtras {
 public:
     using R = Base<T>;
     static constexpr int CP = is_cplx<T>::value ? 1 : 0;
@@ -295,7 +296,9 @@ public:
     void* device_V1() override { flush_swaps(); sync_comm(); return dV1_; }
     std::size_t local_rows() const override { return m_; }
     std::size_t local_cols_h() const { return n_; }
-    void set_pipeline(bool f) { pipeline_ = f; }
+    // (like set_panel_cols: anything in flight is waited for first - an unpipelined product does not wait per panel)
+    void set_pipeline(bool f) { flush_swaps(); sync_comm(); pipeline_ = f; }
+    bool pipeline() const { return pipeline_; }
     // Run-time knobs of the panel pipeline (first-contact self-tuning of bench.py --gpus N: they cannot be tuned without the
     // hardware the job runs on).  Collective: every rank must set the same value at the same point of its call sequence (the
     // panel grid defines which columns one all-reduce carries).  Anything in flight is waited for first; the per-panel
@@ -487,6 +490,7 @@ public:
         allreduce_packed_upper(dA_, block, CHASE_HIP_ROW, agree_vectors ? -1 : CHASE_HIP_COL);
         hip_ok(chase_hip_heevd(ctx_, CP, (int)block, dA_, (long)block, ritzv), "heevd");
         if (agree_vectors) agree_vector(ritzv, block, dA_, block * block);
+        else rr_guard(ritzv, block);
         hv_valid_ = false;
         if (resd_reuse_) {
             // row-type H V and V of the new Ritz vectors without another HEMM / all-reduce / redistribution:
@@ -840,6 +844,36 @@ protected:
         if (agree_group >= 0) coll(chase_hip_grid_bcast(grid_, agree_group, dPack_, n * (n + 1) / 2 * E, 0, 0));
         hip_ok(chase_hip_unpack_upper(ctx_, CP, (int)n, dPack_, A, (long)n, 1), "unpack_upper");
     }
+
+    // Identical input + deterministic eigensolver = identical Ritz vectors on every rank - by construction, not by check: a
+    // rank whose host stages (LAPACK below 384 columns, the leaves and deflation of divide & conquer) run on another CPU or
+    // another BLAS threading may round differently, eigenvectors of clustered Ritz values then differ by O(1) rotations
+    // between grid rows, and the back-transformed block is inconsistent with NO error raised (round-5 advisor).  So the
+    // ranks compare a 64-bit content hash of the eigenvector matrix (one streaming pass over 105 MB at config 4, two
+    // 24-double collectives); on any difference the result of rank (0, 0) is broadcast - round 4's always-correct path.
+    // CHASE_HIP_RR_GUARD=0 skips the check; CHASE_HIP_RR_GUARD_FAULT=<rank> (tests) flips one bit on that rank first.
+    void rr_guard(R* ritzv, std::size_t block)
+    {
+        static const bool on = [] { const char* e = std::getenv("CHASE_HIP_RR_GUARD"); return e ? std::atoi(e) != 0 : true; }();
+        if (!on || nprow_ * npcol_ == 1) return;
+        const char* fe = std::getenv("CHASE_HIP_RR_GUARD_FAULT");          // read per call: a test sets it for one solve
+        const int fault = fe ? std::atoi(fe) : -1;
+        if (fault >= 0 && fault == myrow_ + mycol_ * nprow_) {
+            T one;
+            hip_ok(chase_hip_memcpy_d2h(ctx_, &one, dA_ + (block / 2) * block + block / 3, sizeof(T)), "d2h");
+            one = -one;
+            hip_ok(chase_hip_memcpy_h2d(ctx_, dA_ + (block / 2) * block + block / 3, &one, sizeof(T)), "h2d");
+        }
+        unsigned long long h = 0;
+        hip_ok(chase_hip_hash64(ctx_, CP, (int)block, (int)block, dA_, (long)block, &h), "hash64");
+        int same = 1;
+        coll(chase_hip_grid_agree_equal(grid_, h, &same));
+        if (!same) { ++rr_disagreements_; agree_vector(ritzv, block, dA_, block * block); }
+    }
+    std::size_t rr_disagreements_ = 0;
+public:
+    std::size_t rr_disagreements() const { return rr_disagreements_; }      // eigensolver results that differed between ranks
+protected:
 
     // make a small host vector (and optionally a device matrix) identical on all ranks: broadcast from grid (0, 0)
     void agree_vector(R* host, std::size_t n, T* dev, std::size_t dev_elems)

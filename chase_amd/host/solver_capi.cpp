@@ -202,6 +202,7 @@ int chase_hip_solver_set(chase_hip_solver* s, const char* key, double v)
         else if (name == "device_rng") s->ex->set_device_rng(v != 0);
         else if (name == "panel_cols" && (s->pd || s->pz)) { if (s->pz) s->pz->set_panel_cols((size_t)v); else s->pd->set_panel_cols((size_t)v); }
         else if (name == "panel_rounds" && (s->pd || s->pz)) { if (s->pz) s->pz->set_panel_rounds((int)v); else s->pd->set_panel_rounds((int)v); }
+        else if (name == "pipeline" && (s->pd || s->pz)) { if (s->pz) s->pz->set_pipeline(v != 0); else s->pd->set_pipeline(v != 0); }
         else if (name == "reset_counters") s->ex->reset_counters();
         else rc = chase_hip::set_error(CHASE_HIP_EINVAL, "solver_set: unknown key");
     }); });
@@ -232,6 +233,8 @@ int chase_hip_solver_get(chase_hip_solver* s, const char* key, double* out)
         else if (name == "qr_ortho_check" && (s->pd || s->pz)) *out = s->pz ? s->pz->last_ortho_check() : s->pd->last_ortho_check();
         else if (name == "panel_cols" && (s->pd || s->pz)) *out = (double)(s->pz ? s->pz->panel_cols() : s->pd->panel_cols());
         else if (name == "panel_rounds" && (s->pd || s->pz)) *out = (double)(s->pz ? s->pz->panel_rounds() : s->pd->panel_rounds());
+        else if (name == "pipeline" && (s->pd || s->pz)) *out = (double)(s->pz ? s->pz->pipeline() : s->pd->pipeline());
+        else if (name == "rr_disagreements" && (s->pd || s->pz)) *out = (double)(s->pz ? s->pz->rr_disagreements() : s->pd->rr_disagreements());
         else if (name == "qr_variant") *out = (double)s->ex->last_qr_variant();
         else if (name == "filter_ms") *out = s->ex->filter_ms();
         else if (name == "hemm_calls") *out = (double)s->ex->hemm_calls();

@@ -85,6 +85,9 @@ int chase_hip_grid_event_record_on(chase_hip_grid* g, int group, int slot);  /* 
 int chase_hip_grid_event_wait(chase_hip_grid* g, int slot);                  /* last record of the slot on every stream */
 /* all ranks agree on the maximum of a host integer (control-flow decisions such as the potrf info) */
 int chase_hip_grid_agree_max(chase_hip_grid* g, int* value);
+/* all ranks learn whether they all hold the same 64-bit value (e.g. chase_hip_hash64 of a matrix that every rank computed for
+ * itself and that must be replicated bit for bit): *all_equal = 1 / 0, the same on every rank */
+int chase_hip_grid_agree_equal(chase_hip_grid* g, unsigned long long value, int* all_equal);
 /* point-to-point exchange of device doubles inside `group` — replaces ncclSendrecvWrapper / MPI_Sendrecv
  * (grid/nccl_utils.hpp:271, linalg/distMatrix/distMultiVector.hpp:1944-1958): send to group member peer_send, receive
  * from peer_recv (negative peer or zero count: that half is skipped; both peers == own group rank: local copy).  RCCL:

@@ -18,6 +18,7 @@
 #include <random>
 #include <string>
 #include <vector>
+#include "../chase_amd/host/output_override.hpp"   // Output() under the reference's -DCHASE_OUTPUT: the Impls' own override layer
 
 using std::size_t;
 
@@ -67,7 +68,7 @@ static void jacobi_eig(int n, std::vector<double> A, std::vector<double>& w, std
 // (tests/golden/ref_driver_trace.cpp, compiled in the build container only).  Every virtual call is appended to `calls`
 // with its scalar arguments: that list is the golden call trace.
 template <class BaseT, class ConfigT>
-class CpuMock : public BaseT {
+class CpuMock : public chase_amd::WithOutput<BaseT> {
 public:
     CpuMock(size_t N, size_t nev, size_t nex, std::vector<double> H)
         : N_(N), nev_(nev), nex_(nex), n_(nev + nex), H_(std::move(H)), V1_(N * n_), V2_(N * n_), ritzv_(n_), resid_(n_),

@@ -280,6 +280,40 @@ def scenario_solve_counts(ctx, grid, comm, N, nev, nex, cplx, mb, deg):
     s.close()
 
 
+def scenario_rr_guard(ctx, grid, comm, N, nev, nex, cplx, mb, deg):
+    """Round-5 advisor: Rayleigh-Ritz trusts that every rank's eigensolver returns the same bits from the same input.  With
+    CHASE_HIP_RR_GUARD_FAULT=<rank> one rank's eigenvector matrix is corrupted after heevd: the content-hash comparison
+    (chase_hip_grid_agree_equal) must notice on EVERY rank, fall back to the broadcast of rank (0, 0)'s result, and the solve must
+    end like the undisturbed one - same counts, bitwise equal replicas.  (The test sets the variable; pChaseHip reads it per call.)"""
+    H = O.clement(N, cplx)
+    rl, cl = cd.Layout(N, mb, grid.nprow), cd.Layout(N, mb, grid.npcol)
+    dH = ctx.array(cd.local_block_of(H, rl, cl, grid.myrow, grid.mycol))
+    s = cd.DistSolver(ctx, grid, dH, N, nev, nex, cplx, mb, mb)
+    s.set(deg=deg)
+    fault = os.environ.pop("CHASE_HIP_RR_GUARD_FAULT") if comm.rank == 0 else None
+    comm.barrier()
+    st0 = s.solve()
+    lam0 = s.ritzv[:nev].copy()
+    assert s.get("rr_disagreements") == 0
+    comm.barrier()
+    if comm.rank == 0:
+        os.environ["CHASE_HIP_RR_GUARD_FAULT"] = fault
+    comm.barrier()
+    st1 = s.solve()
+    comm.barrier()
+    lam1 = s.ritzv[:nev].copy()
+    assert s.get("rr_disagreements") == st1["iterations"], (s.get("rr_disagreements"), st1["iterations"])
+    assert (st1["iterations"], st1["filtered_vecs"]) == (st0["iterations"], st0["filtered_vecs"])
+    assert np.array_equal(lam0, lam1) if int(fault) != 0 else np.max(np.abs(lam0 - lam1)) < 1e-9
+    assert np.max(s.recompute_residuals(nev)) < 1e-8
+    objs = comm.all_gather_object((grid.myrow, s.local_V()[:, :nev], lam1))
+    first = {}
+    for (i, blk, lam) in objs:
+        assert np.array_equal(lam, objs[0][2])
+        assert np.array_equal(first.setdefault(i, blk), blk), "column-type replicas differ"
+    s.close()
+
+
 def scenario_knob_switching(ctx, grid, comm, N, nev, nex, cplx, mb, deg):
     """The run-time knobs of the panel pipeline (panel width, K-piece granularity, one / two communication streams:
     chase_amd/autotune.py) switched BETWEEN THE ITERATIONS of a solve, on every rank at the same iteration: iteration and

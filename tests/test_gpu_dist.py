@@ -311,3 +311,10 @@ def test_shared_device_transport_releases_the_ranks_when_one_fails():
     with pytest.raises(AssertionError, match="rank 1 gives up"):
         run_ranks(2, 1, body, transport="shared")
     assert time.time() - t < 60
+
+
+def test_rayleigh_ritz_guard_catches_a_rank_whose_eigensolver_differs(monkeypatch):
+    """one rank of a 2 x 2 grid returns other eigenvectors from heevd (fault injection): every rank notices by the 64-bit
+    content hash and takes rank (0, 0)'s result; the solve ends like the undisturbed one"""
+    monkeypatch.setenv("CHASE_HIP_RR_GUARD_FAULT", "3")
+    run(4, S.scenario_rr_guard, 640, 40, 24, True, 16, 20)
