@@ -48,6 +48,12 @@
 #ifndef CHASE_M3_PIPELINE
 #define CHASE_M3_PIPELINE 1
 #endif
+// round 6: the V-side operand sums of the 3M kernels (br + bi) come from a PRECOMPUTED plane instead of four v_add_f64 per MFMA
+// cluster (on gfx950 fp64 vector adds execute on the matrix unit: ~8 cycles of the pipe each, profiles/r02_mfma_f64_issue.txt).
+// 0 builds round 2-5's loop for comparison (scripts/dev_build_variant.sh).
+#ifndef CHASE_M3_SPLANE
+#define CHASE_M3_SPLANE 1
+#endif
 
 namespace chase_hip {
 
@@ -133,6 +139,9 @@ struct GemmArgs {
     int full_tiles, tail_sk, tail_kchunk;
     double* slabs;
     int glds_ok;                                     // operands are 16-byte addressable: direct global -> LDS copies allowed
+    // 3M kernels: plane of the V-side operand sums br + bi in the kernel's own LDS image - per column tile bn and K step kt one
+    // 4 KB block [8 k][64 columns] of doubles at S + (bn * s_nkt + kt) * 512 (splane_kernel writes it before the launch)
+    const double* S; int s_nkt;
     double alpha_re, alpha_im, beta_re, beta_im;
 };
 
@@ -451,9 +460,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                     sa[u] = (const char*)(p.A + ((long)(kbeg + kk) * p.lda + row0_src) * EPT + (long)half * 128);
                     va[u] = (unsigned)lane * 16u;
                 } else {
-                    const int r = 8 * t + (lane >> 3), ku = (lane & 7) ^ ((r >> 1) & 7);
-                    sa[u] = (const char*)(p.A + ((long)row0_src * p.lda + kbeg) * EPT);
-                    va[u] = (unsigned)(((long)r * p.lda + ku * KPU) * EPT * 8);
+                    // row r = 8 t + lane / 8: the 8 t rows go into the uniform base; the swizzle (r >> 1) & 7 = (4 t + lane / 16) & 7
+                    // depends on t through its parity only, so the lane offsets of copies u and u + 2 are the same register
+                    const int rl = lane >> 3, ku = (lane & 7) ^ ((4 * t + (lane >> 4)) & 7);
+                    sa[u] = (const char*)(p.A + ((long)(row0_src + 8 * t) * p.lda + kbeg) * EPT);
+                    va[u] = (unsigned)(((long)rl * p.lda + ku * KPU) * EPT * 8);
                 }
             }
             #pragma unroll
@@ -473,8 +484,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
             // (profiles/r02_mfma_f64_issue.txt).  M0 = LDS destination of lane 0.  Every LDS-DMA of this kernel goes through
             // here, so the compiler never holds a value of its own in M0.
             auto issue_one = [&](int u, int stage) __attribute__((always_inline)) {
-                d2_t* sA = lds + stage * C_::STAGE_UNITS;
-                d2_t* sB = sA + C_::A_UNITS;
+                // (the plane-fed 3M kernels keep all A stages together, then all B stages: one LDS base register per fragment
+                // pattern reaches every stage through the 16-bit immediate offset of ds_read)
+                constexpr bool SPLIT = CPLX && M3 && CHASE_M3_SPLANE;
+                d2_t* sA = SPLIT ? lds + stage * C_::A_UNITS : lds + stage * C_::STAGE_UNITS;
+                d2_t* sB = SPLIT ? lds + C_::STAGES * C_::A_UNITS + stage * C_::B_UNITS : sA + C_::A_UNITS;
                 if (u < NA) {
                     const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(sA + (wv * NA + u) * 64);
                     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
@@ -546,7 +560,144 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                 mfma_chunk(fA, no_hook);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_chunk(fB, no_hook);
+            } else if constexpr (CPLX && M3 && CHASE_M3_SPLANE) {
+                // 3M software pipeline, round 6: V-side operand sums from the precomputed plane p.S.
+                //   * LDS: the three 24 KB stages + a RING OF TWO 4 KB stages for the plane = 80 KB (two workgroups still fit
+                //     the CU's 160 KB).  S(kt) lives in ring stage kt & 1, image [8 k][64 columns] of doubles, brought in by ONE
+                //     more global -> LDS copy per wave and K step (1 KB of the 4 KB block each, linear: the plane is stored in
+                //     this image).  S(kt + 2) is requested right after the mid-step barrier of step kt (all reads of S(kt)
+                //     have completed by then), BEFORE the copies of tile kt + 3, so that the counted vmcnt of the next step
+                //     covers it: the waits are the ones of rounds 2-5.
+                //   * MFMA order inside a cluster: row tile by row tile (i outer).  An A fragment is then REFILLED IN PLACE
+                //     after its 12 MFMAs like the B fragments after theirs (no second A buffer: 8 registers, which the four
+                //     prefetched sum fragments take); every refill is issued >= 9 MFMAs (576 cycles) before its first reader.
+                //   * per cluster: 24 MFMAs, 2 v_add_f64 (the H-side sums ar +- ai, per wave private rows: they cannot be
+                //     shared) instead of 6, 6 ds_read_b128 + 4 ds_read_b64.
+                // Results are bitwise those of rounds 2-5: the plane holds the same IEEE sums br + bi, the accumulators are
+                // independent of each other, so the MFMA order does not matter.
+                constexpr int G = C_::GLDS_PER_WAVE;
+                constexpr int S_UNITS = 256;                                   // 16-byte units per ring stage (4 KB)
+                d2_t* const sring = lds + C_::STAGES * C_::STAGE_UNITS;
+                const char* ssrc = (const char*)(p.S + ((size_t)bn * (size_t)p.s_nkt + (size_t)(kbeg / BK)) * 512) + wv * 1024;
+                const unsigned vs = (unsigned)lane * 16u;
+                int s_issue = 0;                                               // ring stage the next plane copy fills
+                auto issue_s = [&]() __attribute__((always_inline)) {
+                    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(sring + s_issue * S_UNITS + wv * 64);
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                                 :: "v"(vs), "s"(ssrc), "s"(dst) : "memory");
+                    ssrc += 4096;
+                    s_issue ^= 1;
+                };
+                const int npre = min(nfull, C_::STAGES);
+                issue_s(); issue();                                            // S(0), T(0)
+                if (npre > 1) { issue_s(); issue(); }                          // S(1), T(1)
+                if (npre > 2) issue();                                         // T(2)
+                if (npre == 3)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G + 1) : "memory");
+                else if (npre == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G + 1) : "memory");
+                else                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                auto ld_a = [&](int stage, int ch, int i) __attribute__((always_inline)) -> d2_t {
+                    const d2_t* sA = lds + stage * C_::A_UNITS;
+                    const int ku = 4 * ch + q, r = wrow + 16 * i + c16;
+                    if constexpr (OPA_C) return sA[kidx(r, ku)];
+                    else                 return sA[ku * UM + r];
+                };
+                auto ld_b = [&](int stage, int ch, int j) __attribute__((always_inline)) -> d2_t {
+                    const d2_t* sB = lds + C_::STAGES * C_::A_UNITS + stage * C_::B_UNITS;
+                    return sB[kidx(wcol + 16 * j + c16, 4 * ch + q)];
+                };
+                // sum fragment of column tile j of chunk ch (k = 4 ch + q, column 16 j + c16) in the ring stage `soff` points into:
+                // soff = this lane's byte offset of the ring stage being READ NEXT, toggled (one 32-bit xor) at every mid-step
+                // barrier - ring base 72 KB and stage size 4 KB: bit 12 selects the stage, the lane part stays below 2 KB
+                static_assert(((C_::STAGES * C_::STAGE_UNITS * 16) & 4096) == 0, "ring base must have bit 12 clear");
+                unsigned soff = (unsigned)(C_::STAGES * C_::STAGE_UNITS * 16) + (unsigned)(q * 512 + c16 * 8);
+                auto ld_s = [&](int ch, int j) __attribute__((always_inline)) -> double {
+                    return *(const double*)((const char*)lds + soff + ch * 2048 + j * 128);
+                };
+                d2_t aC[TM], bF[TN];
+                double sS[TN];
+                #pragma unroll
+                for (int i = 0; i < TM; ++i) aC[i] = ld_a(0, 0, i);
+                #pragma unroll
+                for (int j = 0; j < TN; ++j) { bF[j] = ld_b(0, 0, j); sS[j] = ld_s(0, j); }
+                // One MFMA cluster on (aC, bF, sS) while the fragments of (nstage, nch) stream in; `more`: there is a next
+                // chunk.  fill_t: the cluster also requests tile kt+STAGES (its six copies, one per MFMA group, slots 1..6);
+                // fill_s: and first the plane block two K steps ahead (slot 0).
+                auto cluster = [&](int nstage, int nch, auto more_c, auto fill_t_c, auto fill_s_c, int fstage = 0) __attribute__((always_inline)) {
+                    constexpr bool more = decltype(more_c)::value;
+                    constexpr bool fill_t = decltype(fill_t_c)::value;
+                    constexpr bool fill_s = decltype(fill_s_c)::value;
+                    #pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const double sa = OPA_C ? aC[i].x - aC[i].y : aC[i].x + aC[i].y;
+                        #pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            if (!RAGGED || j < jv) {                           // ragged tile: groups past n carry no MFMAs
+                                acc[0][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(bF[j].x, aC[i].x, acc[0][j][i], 0, 0, 0);
+                                acc[1][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(bF[j].y, aC[i].y, acc[1][j][i], 0, 0, 0);
+                                acc[2][j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(sS[j], sa, acc[2][j][i], 0, 0, 0);
+                            }
+                            const int slot = TN * i + j;
+                            if (fill_s && slot == 0) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                issue_s();
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            if (fill_t && slot >= 1 && slot - 1 < NA + NB) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                issue_one(slot - 1, fstage);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            // (the barrier keeps the refills BEHIND their registers' last readers: hoisted above them they
+                            // would need registers of their own - there are none)
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (more && i == TM - 1) { bF[j] = ld_b(nstage, nch, j); sS[j] = ld_s(nch, j); }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (more) aC[i] = ld_a(nstage, nch, i);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                static_assert(TM * TN >= NA + NB + 1, "one copy per (i, j) slot of the cluster");
+                constexpr std::true_type yes{};
+                constexpr std::false_type no{};
+                // one K step on the tile in stage st; fill_t: tile kt+STAGES exists and goes into stage st; fill_s: tile kt+2
+                // exists, its plane block goes into the ring stage this step has just finished reading
+                auto kstep = [&](int kt, int st, auto fill_t_c, auto fill_s_c) __attribute__((always_inline)) {
+                    const int stn = (st + 1 == C_::STAGES) ? 0 : st + 1;
+                    cluster(st, 1, yes, no, no);                               // chunk 0 of tile kt, prefetching its chunk 1
+                    // my reads of stage st and of its ring stage are complete, my copies of tile kt+1 and of its plane block
+                    // have landed; tile kt+2 (requested one step ago) may stay in flight
+                    if (decltype(fill_t_c)::value || kt + 2 < nfull)
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
+                    else
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    soff ^= 4096u;                                             // the other ring stage: tile kt+1's sums
+                    __builtin_amdgcn_sched_barrier(0);
+                    cluster(stn, 0, yes, fill_t_c, fill_s_c, st);              // chunk 1 of tile kt (+ the copies)
+                };
+                int kt = 0;
+                // steady state, three K steps per trip: the stage indices are compile-time constants, so every LDS address is a
+                // loop-invariant register plus an immediate offset (the ring stage of the sums: one xor per K step)
+                if constexpr (C_::STAGES == 3) {
+                    for (; kt + 2 + C_::STAGES < nfull; kt += 3) {
+                        kstep(kt, 0, yes, yes);
+                        kstep(kt + 1, 1, yes, yes);
+                        kstep(kt + 2, 2, yes, yes);
+                    }
+                }
+                int st = 0;                                                    // kt is a multiple of STAGES here
+                for (; kt + C_::STAGES < nfull; ++kt) { kstep(kt, st, yes, yes); st = (st + 1 == C_::STAGES) ? 0 : st + 1; }
+                if (kt + 2 < nfull)                   { kstep(kt, st, no, yes);  st = (st + 1 == C_::STAGES) ? 0 : st + 1; ++kt; }
+                for (; kt + 1 < nfull; ++kt)          { kstep(kt, st, no, no);   st = (st + 1 == C_::STAGES) ? 0 : st + 1; }
+                cluster(st, 1, yes, no, no);                                   // last tile: nothing to publish or prefetch after it
+                __builtin_amdgcn_sched_barrier(0);
+                cluster(st, 1, no, no, no);
             } else if constexpr (CPLX && M3 && CHASE_M3_PIPELINE) {
+                // (rounds 2-5, kept for comparison builds: -DCHASE_M3_SPLANE=0)
                 // 3M software pipeline.  192 accumulator registers leave no room for a second set of fragments, so only
                 // the A fragments (8 registers) are double-buffered; each B fragment is REFILLED IN PLACE with the next
                 // chunk's data right after the six MFMAs that were its last readers, i.e. 18 MFMAs (>1000 cycles) before
@@ -831,6 +982,38 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(const double* __restri
     }
 }
 
+// The plane of V-side operand sums of a 3M launch (GemmArgs::S): for column tile bn (columns col0 = bn * bn_cols .. + 63, clamped
+// to the last valid column like the kernel's own B copies) and K step kt the block S[(bn * nkt + kt) * 512 + kk * 64 + c] =
+// re + im of B[k = 8 kt + kk, col0 + c].  One workgroup per (64 k, column tile): B is read along k (1 KB per wave instruction),
+// transposed through LDS, written along c (512 B per wave instruction).  2.7 GB read + 1.3 GB written at config 4's full width:
+// < 0.1 % of the product it precedes.
+__global__ __launch_bounds__(256) void splane_kernel(const double* __restrict__ B, long ldb, int n, int k, int bn_cols, int nkt,
+                                                     double* __restrict__ S)
+{
+    __shared__ double sm[64][65];
+    const int bn = blockIdx.y, k0 = blockIdx.x * 64, col0 = bn * bn_cols, t = threadIdx.x;
+    #pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int c = 4 * it + (t >> 6), kl = t & 63;
+        const int col = min(col0 + c, n - 1);
+        double v = 0.0;
+        if (k0 + kl < k) { const d2_t b = *(const d2u_t*)(B + ((long)col * ldb + k0 + kl) * 2); v = b.x + b.y; }
+        sm[kl][c] = v;
+    }
+    __syncthreads();
+    #pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int kl = 4 * it + (t >> 6), c = t & 63, kk = k0 + kl;
+        if (kk < k) S[((size_t)bn * nkt + (kk >> 3)) * 512 + (kk & 7) * 64 + c] = sm[kl][c];
+    }
+}
+// bytes of the plane for an m x n x k piece in column tiles of bn_cols (0: whole tiles)
+static size_t splane_bytes(int n, int k, int bn_cols)
+{
+    if (bn_cols <= 0 || bn_cols > 64) bn_cols = 64;
+    return (size_t)((n + bn_cols - 1) / bn_cols) * (size_t)((k + 7) / 8) * 4096;
+}
+
 // three-multiplication scheme for the complex filter products: -1 = not decided yet (CHASE_HIP_GEMM3M, default on)
 static std::atomic<int> g_gemm3m{-1};
 int gemm3m_enabled()
@@ -993,6 +1176,8 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
                 (double)std::max(lda, ldb) * C_::BM * C_::EPT * 8 < 4.0e9;      // per-lane byte offsets are 32-bit
     const unsigned grid = (unsigned)(full + tail * sk);
     const size_t lds_bytes = (size_t)C_::STAGES * C_::STAGE_UNITS * sizeof(d2_t);
+    // 3M kernels: + the ring of two 4 KB stages of the operand-sum plane (80 KB: two workgroups per CU still fit)
+    const size_t lds_bytes3 = lds_bytes + (CHASE_M3_SPLANE ? 2 * 4096 : 0);
     // ragged: some 16-column group of the last column tile lies entirely past n
     const bool ragged = (bn_cols < C_::BN) || (a.gn * C_::BN - n) >= 16;
     // the dynamic-LDS limit is a per-device function attribute: one flag per device (setting it twice is harmless, so a
@@ -1010,17 +1195,31 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
     constexpr bool CAN3M = CPLX;
     const bool want3m = gemm3m_enabled() != 0;
     // the 3M instantiation has no register-staged fallback: whole row tiles, whole K tiles, 16-byte addressable operands
-    const bool ok3m = allow3m && want3m && a.glds_ok && (m % C_::BM == 0) && (k % C_::BK == 0) && (kchunk % C_::BK == 0);
+    bool ok3m = allow3m && want3m && a.glds_ok && (m % C_::BM == 0) && (k % C_::BK == 0) && (kchunk % C_::BK == 0);
+    a.S = nullptr; a.s_nkt = 0;
     if constexpr (CAN3M) {
         static std::atomic<bool> attr3[MAX_DEVICES];
         if (!attr3[dev].load(std::memory_order_relaxed)) {
-            (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, false, CAN3M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, true, CAN3M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, false, CAN3M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes3);
+            (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<CPLX, OPA_C, TAG, true, CAN3M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes3);
             attr3[dev].store(true, std::memory_order_relaxed);
         }
+        if (ok3m && CHASE_M3_SPLANE) {
+            // the operand-sum plane sits behind the slabs in the caller's workspace (gemm_f64_ws_need counts it); written on the
+            // same stream right before the product
+            const size_t off = (pl.ws_bytes + 255) & ~(size_t)255, sb = splane_bytes(n, k, bn_cols);
+            if (ws == nullptr) ok3m = false;                                   // no workspace: four products
+            else if (off + sb > ws_bytes) return GEMM_F64_EWORKSPACE;
+            else {
+                double* S = (double*)((char*)ws + off);
+                hipLaunchKernelGGL(splane_kernel, dim3((unsigned)((k + 63) / 64), (unsigned)a.gn), dim3(256), 0, st, B, ldb, n, k,
+                                   bn_cols, k / C_::BK, S);
+                a.S = S; a.s_nkt = k / C_::BK;
+            }
+        }
         if (ok3m) {
-            if (ragged) hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG, true, CAN3M>), dim3(grid), dim3(256), lds_bytes, st, a);
-            else        hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG, false, CAN3M>), dim3(grid), dim3(256), lds_bytes, st, a);
+            if (ragged) hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG, true, CAN3M>), dim3(grid), dim3(256), lds_bytes3, st, a);
+            else        hipLaunchKernelGGL((gemm_f64_kernel<CPLX, OPA_C, TAG, false, CAN3M>), dim3(grid), dim3(256), lds_bytes3, st, a);
         }
     }
     if (!(CAN3M && ok3m)) {
@@ -1147,6 +1346,9 @@ static size_t ws_need(int m, int n, int k, int num_cu, int min_rounds)
                           : plan_part<CPLX, OPA_C, false>(m, pc.n, k, pc.bn_cols, num_cu, min_rounds).ws_bytes;
         } else {
             b = plan_part<CPLX, OPA_C, false>(m, pc.n, k, pc.bn_cols, num_cu, min_rounds).ws_bytes;
+            // + the operand-sum plane of a 3M launch (whether a product runs on three multiplications depends on the phase
+            // tag, which the sizing does not know: counted for every complex product while 3M is enabled)
+            if (CHASE_M3_SPLANE && gemm3m_enabled() != 0) b = ((b + 255) & ~(size_t)255) + splane_bytes(pc.n, k, pc.bn_cols);
         }
         need = std::max(need, b);
     }

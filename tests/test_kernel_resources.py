@@ -12,7 +12,11 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-PARKED = ("ILb1ELb1ELi0ELb1ELb1ELb0E", "ILb1ELb1ELi1ELb1ELb1ELb0E")     # <cplx, op=C, tag 0 / 1, ragged, 3M, not narrow>
+# Round 6 (plane-fed 3M loop, 80 KB of LDS, sum fragments next to 192 accumulators): the four RAGGED 3M instantiations park up to
+# five registers the same way (stores before the K loops, loads after them); the whole-tile ones - 99 % of the filter's time - have
+# no scratch at all.
+PARKED = ("ILb1ELb1ELi0ELb1ELb1ELb0E", "ILb1ELb1ELi1ELb1ELb1ELb0E",     # <cplx, op=C, tag 0 / 1, ragged, 3M, not narrow>
+          "ILb1ELb0ELi0ELb1ELb1ELb0E", "ILb1ELb0ELi1ELb1ELb1ELb0E")     # <cplx, op=N, tag 0 / 1, ragged, 3M, not narrow>
 
 
 def kernel_bodies(asm):
@@ -44,7 +48,7 @@ def test_no_gemm_instantiation_spills_inside_a_loop(tmp_path):
         seen += 1
         scratch = [k for k, l in enumerate(lines) if re.match(r"\s+(scratch_|buffer_(load|store)\w* .*offen)", l)]
         if any(tag in name for tag in PARKED):
-            assert 0 < len(scratch) <= 2, (name, len(scratch))              # one store + one load of the parked register
+            assert 0 < len(scratch) <= 10, (name, len(scratch))             # stores + loads of the parked registers
         else:
             assert not scratch, (name, [lines[k] for k in scratch[:4]])
         for k in scratch:
