@@ -40,7 +40,13 @@ def check_common(d, n_gpus, steps, warmup):
 def test_single_gpu_line_keeps_the_contract():
     d = run_bench("--workload", "cfg2", "--steps", "9", "--warmup", "0", "--cpu-budget", "3")
     check_common(d, 1, 9, 0)
-    assert d["iterations_per_solve"] == 9 and d["filtered_vecs_per_solve"] == 101708        # the oracle's counts for config 2
+    # the oracle's solve of config 2 at full size (tests/golden/oracle_cfg2_fullsize.json; the single-GPU Impl takes it count for
+    # count from the oracle's matrix and start block, tests/test_gpu_fullsize.py): the bench workload differs from it by the
+    # 1e-6 perturbation and the device generator's start block - same iterations, filtered vectors within 2 % (observed: 101 708
+    # against the oracle's 102 614)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_cfg2_fullsize.json")))["unperturbed"]
+    assert d["iterations_per_solve"] == gold["iterations"]
+    assert abs(d["filtered_vecs_per_solve"] - gold["filtered_vecs"]) <= 0.02 * gold["filtered_vecs"], d["filtered_vecs_per_solve"]
     assert d["roofline"]["frac"] > 0.5                                                       # a fallback path would not get here
     assert 1.0 < d["solve_seconds"] < 6.0 and d["eigenpairs_per_sec"] > 80                   # the solve's own seconds (2.5 s), no bench waits in them
     c = d["cpu_baseline"]

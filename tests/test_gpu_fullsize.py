@@ -77,6 +77,48 @@ def test_cfg3_shape_at_full_size_takes_the_oracles_path(nprow, npcol, nb, fixtur
     assert rec["eigenvalues_bitwise_equal_on_all_ranks"] and rec["eigenvector_replicas_bitwise_equal"]
 
 
+def test_cfg2_at_full_size_takes_the_oracles_path():
+    """BASELINE configs[1] AT FULL SIZE on the single-GPU Impl (N = 16384 complex Hermitian, nev = 512, nex = 128 - the only
+    single-GPU configuration besides the headline) against an INDEPENDENT solve: the CPU oracle in its ChASECPU form
+    (tests/golden/make_oracle_cfg2_fullsize.py -> oracle_cfg2_fullsize.json, 25 CPU-minutes here) on the unperturbed
+    Clement-type matrix x 100 / N from the reference's start block (mt19937(1337), one column-major fill,
+    chase_cpu.hpp:296-309).  ChaseHip must take the oracle's path COUNT FOR COUNT - iterations, filtered vectors - and pass what
+    tests/chase_serial_solve.cpp:36-140 asserts: the known spectrum, independently recomputed residuals, orthonormal vectors.
+    (Round 5 pinned config 2's counts to the builder's own runs only.)"""
+    import numpy as np
+    from chase_amd.capi import Context, Solver
+    from oracle import chase_oracle as O
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_cfg2_fullsize.json")))
+    N, nev, nex = gold["N"], gold["nev"], gold["nex"]
+    assert (N, nev, nex, gold["complex"]) == (16384, 512, 128, True)
+    g = gold["unperturbed"]
+    H = O.clement(N, True, perturb=0)
+    H *= 100.0 / N
+    with Context(0) as ctx:
+        s = Solver(ctx, H, nev, nex)
+        del H
+        s.set(device_rng=0, tol=g["tol"], deg=g["deg"])                    # the reference's host generator: the oracle's start block
+        st = s.solve()
+        lam = s.ritzv[:nev].copy()
+        exact = (100.0 / N) * (-N + 2.0 * np.arange(nev))
+        rec = {"workload": "cfg2_unperturbed_oracle_pinned", "grid": "1x1", "iterations": st["iterations"],
+               "filtered_vecs": st["filtered_vecs"], "max_abs_dev_from_analytic": float(np.max(np.abs(np.sort(lam) - exact))),
+               "max_resid": float(np.max(s.resid()[:nev])), "max_resid_recomputed": float(np.max(s.recompute_residuals(nev))),
+               "lambda_sum": float(np.sum(lam)), "oracle": {k: g[k] for k in ("iterations", "filtered_vecs", "max_resid", "lambda_sum")}}
+        V = s.V[:, :nev]
+        rec["orthogonality"] = float(O.orthogonality(V))
+        s.close()
+    with open(os.path.join(OUT, "fullsize_cfg2_oracle_pinned_1x1.json"), "w") as f:
+        json.dump(rec, f)
+    print(json.dumps(rec), flush=True)
+    assert rec["iterations"] == g["iterations"], (rec["iterations"], g["iterations"])
+    assert rec["filtered_vecs"] == g["filtered_vecs"], (rec["filtered_vecs"], g["filtered_vecs"])
+    assert rec["max_abs_dev_from_analytic"] < 1e-8 and g["max_abs_dev_from_analytic"] < 1e-8
+    assert abs(rec["lambda_sum"] - g["lambda_sum"]) < 1e-7
+    assert rec["max_resid"] <= 1e-8 and rec["max_resid_recomputed"] <= 1e-8 and rec["orthogonality"] < 1e-9
+    assert np.all(np.diff(lam) >= 0)
+
+
 @pytest.mark.parametrize("fixture", ["oracle_cfg5_small_synthetic_bse_4x2.json", "oracle_cfg5_fullsize_synthetic_bse_4x2.json"])
 def test_cfg5_shape_at_full_size_against_the_oracle(fixture):
     """BASELINE configs[4]'s shape AT FULL SIZE (N = 32768 complex pseudo-Hermitian, nev = 256, nex = 64, 4 x 2 block grid,
