@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include <vector>
 #include "../../include/chase_hip_grid.h"
 #include "ctx.h"
@@ -47,7 +50,23 @@ struct chase_hip_grid {
     chase_hip_host_bcast_fn h_bcast = nullptr;
     chase_hip_host_sendrecv_fn h_sendrecv = nullptr;
     void* h_user = nullptr;
-    double* scal_dev = nullptr;                        // one double for agree_max
+    double* scal_dev = nullptr;                        // scratch of the agreement collectives (32 doubles)
+    // Failure surface of the RCCL transport (round 6; the reference exits on the first NCCL error, grid/nccl_utils.hpp:13-26).
+    // A watchdog thread polls ncclCommGetAsyncError on both communicators and the age of the newest unfinished collective
+    // (wd_ev: recorded behind every collective on its communication stream); on an asynchronous error - a dead peer - or after
+    // CHASE_HIP_FABRIC_TIMEOUT_S (default 600) without progress it ABORTS both communicators (their kernels then leave the
+    // device, whatever the host is blocked in returns) and latches `failed`: every later grid call returns CHASE_HIP_ECOMM with
+    // fail_text, which the Impls turn into an exception - the rank process ends non-zero instead of hanging.
+    std::thread watchdog;
+    std::atomic<bool> wd_stop{false};
+    std::atomic<int> failed{0};
+    std::mutex nccl_mu;                                // enqueue calls vs. the watchdog's abort
+    char fail_text[256] = {0};
+    hipEvent_t wd_ev[2] = {nullptr, nullptr};
+    std::atomic<long long> wd_issue_ns[2];             // when the newest collective of stream i was enqueued (0: none yet)
+    double timeout_s = 600.0;
+    int rccl_failed();                                 // != 0: sets the error text and returns CHASE_HIP_ECOMM
+    int rccl_issued(int si);                           // bookkeeping behind an enqueued collective
     std::vector<hipEvent_t> slots[2];                  // per-panel 'all-reduce done' events (pipelined HEMM), per stream
     // profiling of exposed communication: every wait of the compute stream on the communication stream is bracketed by
     // two timing events; their distance is the time the compute stream had nothing to do but wait

@@ -121,6 +121,65 @@ int chase_hip_grid::collect_exposed()
     return 0;
 }
 
+int chase_hip_grid::rccl_failed()
+{
+    if (!failed.load(std::memory_order_acquire)) return 0;
+    return set_error(CHASE_HIP_ECOMM, fail_text[0] ? fail_text : "RCCL transport failed");
+}
+static long long now_ns()
+{
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+int chase_hip_grid::rccl_issued(int si)
+{
+    HIPCHK(hipEventRecord(wd_ev[si], comm_stream[si]));
+    wd_issue_ns[si].store(now_ns(), std::memory_order_release);
+    return 0;
+}
+// the watchdog of an RCCL grid (see grid.h)
+static void rccl_watchdog(chase_hip_grid* g)
+{
+    (void)hipSetDevice(g->ctx->device);
+    auto fail = [&](const char* what) {
+        snprintf(g->fail_text, sizeof g->fail_text, "RCCL transport: %s (rank %d of the %d x %d grid): communicators aborted", what,
+                 g->rank, g->nprow, g->npcol);
+        g->failed.store(1, std::memory_order_release);
+        // an enqueue call in flight on the main thread gets two seconds to return; then abort regardless (a call blocked on a
+        // dead peer never returns by itself)
+        std::unique_lock<std::mutex> lk(g->nccl_mu, std::defer_lock);
+        for (int i = 0; i < 200 && !lk.try_lock(); ++i) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        for (int i = 0; i < 2; ++i)
+            if (g->comm[i]) { (void)ncclCommAbort(g->comm[i]); g->comm[i] = nullptr; }
+        fprintf(stderr, "chase_hip: %s\n", g->fail_text);
+    };
+    while (!g->wd_stop.load(std::memory_order_acquire)) {
+        for (int i = 0; i < 2 && !g->failed.load(); ++i) {
+            ncclComm_t c = g->comm[i];
+            if (!c) continue;
+            ncclResult_t ar = ncclSuccess;
+            if (ncclCommGetAsyncError(c, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+                char b[160];
+                snprintf(b, sizeof b, "asynchronous error on the %s communicator: %s", i == CHASE_HIP_ROW ? "row" : "column",
+                         ncclGetErrorString(ar));
+                fail(b);
+            }
+        }
+        for (int si = 0; si < 2 && !g->failed.load(); ++si) {
+            const long long t0 = g->wd_issue_ns[si].load(std::memory_order_acquire);
+            if (t0 == 0 || !g->wd_ev[si]) continue;
+            if (hipEventQuery(g->wd_ev[si]) != hipErrorNotReady) continue;
+            if ((now_ns() - t0) * 1e-9 > g->timeout_s) {
+                char b[160];
+                snprintf(b, sizeof b, "a collective has not finished %.0f s after it was issued (CHASE_HIP_FABRIC_TIMEOUT_S)", g->timeout_s);
+                fail(b);
+            }
+        }
+        if (g->failed.load()) return;
+        for (int i = 0; i < 10 && !g->wd_stop.load(std::memory_order_acquire); ++i)
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    }
+}
+
 extern "C" {
 
 int chase_hip_rccl_unique_id(char id[CHASE_HIP_UNIQUE_ID_BYTES])
@@ -172,6 +231,15 @@ int chase_hip_grid_create_rccl(chase_hip_grid** out, chase_hip_ctx* ctx, int npr
             if (g->comm[i]) { ncclCommAbort(g->comm[i]); g->comm[i] = nullptr; }
         chase_hip_grid_destroy(g);
         return rc;
+    }
+    if (g->comm[0] || g->comm[1]) {
+        if (const char* e = getenv("CHASE_HIP_FABRIC_TIMEOUT_S")) { const double t = atof(e); if (t > 0) g->timeout_s = t; }
+        for (int i = 0; i < 2; ++i) {
+            g->wd_issue_ns[i].store(0);
+            if (hipEventCreateWithFlags(&g->wd_ev[i], hipEventDisableTiming) != hipSuccess) g->wd_ev[i] = nullptr;
+        }
+        static const bool off = [] { const char* e = getenv("CHASE_HIP_RCCL_WATCHDOG"); return e && atoi(e) == 0; }();
+        if (!off && g->wd_ev[0] && g->wd_ev[1]) g->watchdog = std::thread(rccl_watchdog, g);
     }
     *out = g;
     return 0;
@@ -232,10 +300,14 @@ int chase_hip_grid_destroy(chase_hip_grid* g)
 {
     if (!g) return 0;
     if (g->ctx) hipSetDevice(g->ctx->device);
+    g->wd_stop.store(true, std::memory_order_release);
+    if (g->watchdog.joinable()) g->watchdog.join();
     for (int i = 0; i < 2; ++i)
         if (g->comm_stream[i]) (void)hipStreamSynchronize(g->comm_stream[i]);
     for (int i = 0; i < 2; ++i)
-        if (g->comm[i]) (void)ncclCommDestroy(g->comm[i]);
+        if (g->comm[i]) (void)ncclCommDestroy(g->comm[i]);       // (aborted communicators are nullptr already)
+    for (int i = 0; i < 2; ++i)
+        if (g->wd_ev[i]) (void)hipEventDestroy(g->wd_ev[i]);
     if (g->scal_dev) (void)hipFree(g->scal_dev);
     if (g->fab_ready) (void)hipEventDestroy(g->fab_ready);
     if (g->fab_done) (void)hipEventDestroy(g->fab_done);
@@ -290,6 +362,7 @@ static int collective(chase_hip_grid* g, int mode, int group, void* dev, size_t 
     if (group != CHASE_HIP_ROW && group != CHASE_HIP_COL) return set_error(CHASE_HIP_EINVAL, "collective: bad group");
     if (count == 0 || !g->active(group)) return 0;
     if (mode == 1 && (root < 0 || root >= g->group_size(group))) return set_error(CHASE_HIP_EINVAL, "bcast: bad root");
+    if (int f = g->rccl_failed()) return f;
     chase_hip_ctx* c = g->ctx;
     if (c->oplog_on) c->oplog_add(mode == 0 ? "allreduce" : "bcast", group, (long)count, mode == 0 ? 0 : root, async);
     if (g->async_transport()) {
@@ -298,8 +371,11 @@ static int collective(chase_hip_grid* g, int mode, int group, void* dev, size_t 
         HIPCHK(hipEventRecord(g->ev_compute, c->stream));
         HIPCHK(hipStreamWaitEvent(cs, g->ev_compute, 0));
         if (g->use_rccl) {
+            std::lock_guard<std::mutex> lk(g->nccl_mu);
+            if (int f = g->rccl_failed()) return f;
             if (mode == 0) NCCLCHK(ncclAllReduce(dev, dev, count, ncclDouble, ncclSum, g->comm[group], cs));
             else NCCLCHK(ncclBroadcast(dev, dev, count, ncclDouble, root, g->comm[group], cs));
+            if (int f = g->rccl_issued(g->stream_index(group))) return f;
         } else if (g->loopback_touch || g->lb_busbw_GBps > 0) {
             const int p = g->group_size(group);
             const double wire = (mode == 0 ? 2.0 * (p - 1) / p : 1.0) * (double)count * sizeof(double);
@@ -338,6 +414,7 @@ int chase_hip_grid_wait(chase_hip_grid* g)
 {
     if (!g) return set_error(CHASE_HIP_EINVAL, "grid_wait: NULL grid");
     if (!g->async_transport()) return 0;
+    if (int f = g->rccl_failed()) return f;
     for (int i = 0; i < 2; ++i) {
         if (!g->pending[i]) continue;                   // nothing issued on that stream since the last wait
         HIPCHK(hipEventRecord(g->ev_comm[i], g->comm_stream[i]));
@@ -381,6 +458,7 @@ int chase_hip_grid_event_wait(chase_hip_grid* g, int slot)
     if (!g || slot < 0) return set_error(CHASE_HIP_EINVAL, "event_wait: bad argument");
     if (g->ctx->oplog_on) g->ctx->oplog_add("event_wait", slot, 0, 0, 0);
     if (!g->async_transport()) return 0;
+    if (int f = g->rccl_failed()) return f;
     for (int si = 0; si < 2; ++si) {
         if (slot >= (int)g->slots[si].size() || !g->slots[si][slot]) continue;
         int rc = g->wait_on(g->slots[si][slot]);
@@ -412,6 +490,7 @@ int chase_hip_grid_agree_max(chase_hip_grid* g, int* value)
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(v, g->scal_dev, sizeof v, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        if (int f = g->rccl_failed()) return f;           // aborted meanwhile: what came back is not a sum
         for (int i = 0; i < sz; ++i) cur = std::max(cur, (int)std::lround(v[i]));
     }
     *value = cur;
@@ -444,6 +523,7 @@ int chase_hip_grid_agree_equal(chase_hip_grid* g, unsigned long long value, int*
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(v, g->scal_dev, sizeof v, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        if (int f = g->rccl_failed()) return f;
         for (int i = 0; i < sz; ++i)
             if (v[i] != v[0] || v[8 + i] != v[8] || v[16 + i] != 0.0) bad = 1;
     }
@@ -488,14 +568,20 @@ int chase_hip_grid_sendrecv(chase_hip_grid* g, int group, const void* sendbuf, s
         return chase_hip_grid_wait(g);
     }
     if (g->use_rccl) {
+        if (int f = g->rccl_failed()) return f;
         if (!g->comm[group]) return set_error(CHASE_HIP_ECOMM, "sendrecv: group has no communicator");
         hipStream_t cs = g->stream_of(group);
         HIPCHK(hipEventRecord(g->ev_compute, c->stream));
         HIPCHK(hipStreamWaitEvent(cs, g->ev_compute, 0));
-        NCCLCHK(ncclGroupStart());
-        if (peer_send >= 0) NCCLCHK(ncclSend(sendbuf, sendcount, ncclDouble, peer_send, g->comm[group], cs));
-        if (peer_recv >= 0) NCCLCHK(ncclRecv(recvbuf, recvcount, ncclDouble, peer_recv, g->comm[group], cs));
-        NCCLCHK(ncclGroupEnd());
+        {
+            std::lock_guard<std::mutex> lk(g->nccl_mu);
+            if (int f = g->rccl_failed()) return f;
+            NCCLCHK(ncclGroupStart());
+            if (peer_send >= 0) NCCLCHK(ncclSend(sendbuf, sendcount, ncclDouble, peer_send, g->comm[group], cs));
+            if (peer_recv >= 0) NCCLCHK(ncclRecv(recvbuf, recvcount, ncclDouble, peer_recv, g->comm[group], cs));
+            NCCLCHK(ncclGroupEnd());
+            if (int f = g->rccl_issued(g->stream_index(group))) return f;
+        }
         g->pending[g->stream_index(group)] = true;
         return chase_hip_grid_wait(g);
     }

@@ -290,7 +290,10 @@ def scenario_rr_guard(ctx, grid, comm, N, nev, nex, cplx, mb, deg):
     dH = ctx.array(cd.local_block_of(H, rl, cl, grid.myrow, grid.mycol))
     s = cd.DistSolver(ctx, grid, dH, N, nev, nex, cplx, mb, mb)
     s.set(deg=deg)
-    fault = os.environ.pop("CHASE_HIP_RR_GUARD_FAULT") if comm.rank == 0 else None
+    fault = os.environ["CHASE_HIP_RR_GUARD_FAULT"]                         # every rank thread reads it, rank 0 unsets it
+    comm.barrier()
+    if comm.rank == 0:
+        del os.environ["CHASE_HIP_RR_GUARD_FAULT"]
     comm.barrier()
     st0 = s.solve()
     lam0 = s.ritzv[:nev].copy()
@@ -840,6 +843,37 @@ def scenario_comm_latency(ctx, grid, comm, reps=200):
         print("COMM_LATENCY ms per collective:", res[0], flush=True)
 
 
+def scenario_peer_dies(ctx, grid, comm, N, nev, nex):
+    """Round-5 verdict: a dead peer must not be a hang.  The LAST rank leaves the job abruptly (os._exit, no clean-up - what a
+    crashed rank looks like) from the iteration hook of its second iteration; every other rank must get an exception out of its
+    solve - the RCCL watchdog of grid.hip saw the asynchronous error (or the timeout), aborted the communicators - and leaves with
+    exit code 42 itself.  The test (tests/test_gpu_processes.py) checks codes, time and the message."""
+    import time
+    from chase_amd.capi import ChaseHipError
+    H = O.clement(N, True)
+    rl, cl = cd.Layout(N, 0, grid.nprow), cd.Layout(N, 0, grid.npcol)
+    dH = ctx.array(cd.local_block_of(H, rl, cl, grid.myrow, grid.mycol))
+    s = cd.DistSolver(ctx, grid, dH, N, nev, nex, True, 0, 0)
+    s.set(deg=20)
+    victim = comm.rank == comm.world - 1
+
+    def hook(it, filtered, locked, unconverged):
+        if victim and it >= 1:
+            sys.stdout.flush()
+            os._exit(7)
+        return False
+    s.set_iteration_hook(hook)
+    t = time.monotonic()
+    try:
+        s.solve()
+    except ChaseHipError as e:
+        print("PEER_DEATH_SURFACED after %.1f s: %s" % (time.monotonic() - t, e), flush=True)
+        sys.stderr.flush()
+        os._exit(42)                                                       # (no collective clean-up with a dead peer)
+    print("solve returned although a peer died", flush=True)
+    os._exit(3)
+
+
 def run_named(scen, ctx, grid, comm, argv):
     """command-line form of the scenarios (tests/dist_worker.py)"""
     z = lambda a: a == "z"
@@ -867,6 +901,8 @@ def run_named(scen, ctx, grid, comm, argv):
         scenario_cshim(ctx, grid, comm, z(argv[0]), int(argv[1]))
     elif scen == "p2p":
         scenario_p2p(ctx, grid, comm)
+    elif scen == "peer_dies":
+        scenario_peer_dies(ctx, grid, comm, int(argv[0]), int(argv[1]), int(argv[2]))
     elif scen == "pseudo_ops":
         scenario_pseudo_ops(ctx, grid, comm, int(argv[0]))
     elif scen == "pseudo_solve_real":
