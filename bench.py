@@ -272,6 +272,9 @@ class StepTimer:
 
     def start_if_due(self):
         if self.t0 is None and self.boundary == self.warmup:
+            # device work the solve has queued up to this boundary (deferred swaps, asynchronous launches) is the SOLVE's time:
+            # drain it first, and count as a bench wait only what comes after (round-5 advisor)
+            self.sync()
             t = time.perf_counter()
             if self.before_timed is not None:
                 self.before_timed()             # (joins the CPU-baseline child: seconds that are not the solve's)
@@ -291,9 +294,11 @@ class StepTimer:
             self.per_iter.append((self.solve_index, it, filtered, now - self._last))
             self._last = now
             if self.boundary == self.warmup + self.steps:
+                self.sync()                    # (the solve's own queued work, see start_if_due)
+                drained = time.perf_counter()
                 self.t1, self.c1 = self._bracket()
                 if self.in_solve:
-                    self.outside[self.solve_index] = self.outside.get(self.solve_index, 0.0) + (self.t1 - now)
+                    self.outside[self.solve_index] = self.outside.get(self.solve_index, 0.0) + (self.t1 - drained)
         self.start_if_due()
         # never cut a solve short: the solve in flight when the timed region ends runs to completion (its remaining
         # iterations are the cheap ones), so that the LAST solve is always a complete one and the independent residual

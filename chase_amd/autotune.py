@@ -32,18 +32,39 @@ def cost(rec):
     return rec["seconds"] + SMALL_PER_PRODUCT * rec.get("small_collective_us", 0.0) * 1e-6
 
 
-def plan(base, budget):
+def streams_candidate_enabled():
+    """The two-communication-stream candidate launches the row and the column communicator's collectives concurrently from one
+    process, so their device execution order may differ between ranks; it has only ever run over RCCL's socket transport (four
+    processes on one GPU).  Until it has been seen on xGMI it is OPT-IN (CHASE_HIP_AUTOTUNE_STREAMS=1) - round-5 advisor; a trial
+    that does hang ends in the RCCL watchdog's CHASE_HIP_ECOMM after CHASE_HIP_FABRIC_TIMEOUT_S (grid.hip), not in a re-exec."""
+    import os
+    return os.environ.get("CHASE_HIP_AUTOTUNE_STREAMS", "0") == "1"
+
+
+def plan(base, budget, streams=None, skipped=None):
     """One-factor-at-a-time schedule as a list of stages; a stage is (knob, [values to try]); the base value of a knob is always
-    measured (first trial overall, then implicitly as the incumbent).  budget = number of trials the caller can afford."""
+    measured (first trial overall, then implicitly as the incumbent).  budget = number of trials the caller can afford.
+    streams: may the schedule try TWO communication streams (None: streams_candidate_enabled()); going from two streams back to
+    one is always allowed.  skipped (a list): receives what the schedule left out and why."""
+    if streams is None:
+        streams = streams_candidate_enabled()
     stages = [("panel_cols", [p for p in PANELS if p != base["panel_cols"]]),
-              ("panel_rounds", [0 if base["panel_rounds"] else 4]),
-              ("comm_streams", [1 if base["comm_streams"] == 2 else 2])]
+              ("panel_rounds", [0 if base["panel_rounds"] else 4])]
+    if base["comm_streams"] == 2:
+        stages.append(("comm_streams", [1]))
+    elif streams:
+        stages.append(("comm_streams", [2]))
+    elif skipped is not None:
+        skipped.append({"knob": "comm_streams", "value": 2, "why": "opt-in: CHASE_HIP_AUTOTUNE_STREAMS=1 (never run on xGMI)"})
     out, left = [], budget - 1                # one trial is the base setting itself
     for knob, values in stages:
         take = values[:max(left, 0)]
         if take:
             out.append((knob, take))
             left -= len(take)
+        if skipped is not None:
+            for v in values[len(take):]:
+                skipped.append({"knob": knob, "value": v, "why": "trial budget (%d)" % budget})
     return out
 
 
@@ -59,7 +80,7 @@ def better(a, b):
     return a["exposed_ms"] < b["exposed_ms"] * (1.0 - TIE) and ca <= cb * (1.0 + TIE)
 
 
-def tune(base, budget, measure):
+def tune(base, budget, measure, streams=None, skipped=None):
     """measure(setting) -> {"seconds", "exposed_ms"} (already agreed between the ranks).  Returns (best setting, table)."""
     best = dict(base)
     rec = measure(best)
@@ -67,7 +88,7 @@ def tune(base, budget, measure):
     best_rec = rec
     if budget < 2:
         return best, table
-    for knob, values in plan(base, budget):
+    for knob, values in plan(base, budget, streams, skipped):
         for v in values:
             cand = dict(best)
             cand[knob] = v
@@ -152,9 +173,10 @@ def first_contact(s, ctx, grid, comm, nevex, budget=5, steps=2, log=None):
         return rec
 
     base = current_setting(s, grid)
-    best, table = tune(base, budget, measure)
+    skipped = []
+    best, table = tune(base, budget, measure, skipped=skipped)
     apply_setting(s, grid, best)
-    return {"base": base, "chosen": best,
+    return {"base": base, "chosen": best, "skipped": skipped,
             "unit": "cost = seconds per full-width distributed HEMM + %.1f x the latency of a small synchronous collective (max over "
                     "ranks); one factor at a time" % SMALL_PER_PRODUCT,
             "trials": table}

@@ -332,7 +332,9 @@ public:
         const R tol = (R)config_.GetTol();
         // the window: 1e-3 tol, or - for a tight tolerance / a large norm - the scale of the rounding gap itself, which does not
         // depend on tol (measured at config 4: 4e-15 = 0.2 eps ||H||; ||H|| from the Lanczos upper bound; the advisor's finding)
-        const R window = std::max((R)1e-3 * tol, (R)4 * std::numeric_limits<R>::epsilon() * norm_h_);
+        // capped at tol / 2 (round-5 advisor): for ||H|| >= 1e5 tol / eps the rounding-gap term alone would exceed tol and every
+        // converged residual would be re-taken in every iteration
+        const R window = std::min(std::max((R)1e-3 * tol, (R)4 * std::numeric_limits<R>::epsilon() * norm_h_), (R)0.5 * tol);
         std::vector<std::size_t> idx;
         if (forced_recheck_ >= 0) {                           // single-rank replay: as many as the recording re-took
             for (std::size_t j = 0; j < std::min<std::size_t>((std::size_t)forced_recheck_, sub); ++j) idx.push_back(j);

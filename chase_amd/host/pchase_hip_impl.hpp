@@ -557,7 +557,9 @@ public:
         // the window is the larger of 1e-3 tol and the rounding gap between the three-product / cached residual and the
         // reference's fresh one (measured at config 4: 0.2 eps ||H||; window 4 eps ||H||, ||H|| from the Lanczos upper bound;
         // independent of tol - the advisor's finding)
-        const R window = std::max((R)1e-3 * tol, (R)4 * std::numeric_limits<R>::epsilon() * norm_h_);
+        // capped at tol / 2 (round-5 advisor): for ||H|| >= 1e5 tol / eps the rounding-gap term alone would exceed tol and every
+        // converged residual would be re-taken in every iteration
+        const R window = std::min(std::max((R)1e-3 * tol, (R)4 * std::numeric_limits<R>::epsilon() * norm_h_), (R)0.5 * tol);
         std::vector<std::size_t> idx;
         if (forced_recheck_ >= 0) {                                        // single-rank replay: as many as the recording re-took
             for (std::size_t j = 0; j < std::min<std::size_t>((std::size_t)forced_recheck_, sub); ++j) idx.push_back(j);

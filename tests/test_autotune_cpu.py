@@ -46,8 +46,16 @@ def test_budget_cuts_the_schedule_from_the_end():
     best, _ = A.tune(BASE, 3, m)
     assert calls == [(256, 4, 2), (128, 4, 2), (512, 4, 2)] and best["panel_cols"] == 128
     assert A.plan(BASE, 5) == [("panel_cols", [128, 512]), ("panel_rounds", [0]), ("comm_streams", [1])]
-    assert A.plan({"panel_cols": 512, "panel_rounds": 0, "comm_streams": 1}, 9) == [("panel_cols", [128, 256]), ("panel_rounds", [4]),
-                                                                                   ("comm_streams", [2])]
+    one = {"panel_cols": 512, "panel_rounds": 0, "comm_streams": 1}
+    assert A.plan(one, 9, streams=True) == [("panel_cols", [128, 256]), ("panel_rounds", [4]), ("comm_streams", [2])]
+    # round-5 advisor: TWO communication streams are tried only when asked for (CHASE_HIP_AUTOTUNE_STREAMS=1; never seen on
+    # xGMI); what the schedule leaves out - and why - is recorded for the bench's JSON line
+    skipped = []
+    assert A.plan(one, 9, streams=False, skipped=skipped) == [("panel_cols", [128, 256]), ("panel_rounds", [4])]
+    assert skipped == [{"knob": "comm_streams", "value": 2, "why": "opt-in: CHASE_HIP_AUTOTUNE_STREAMS=1 (never run on xGMI)"}]
+    skipped = []
+    assert A.plan(one, 2, streams=True, skipped=skipped) == [("panel_cols", [128])]
+    assert [(k["knob"], k["value"]) for k in skipped] == [("panel_cols", 256), ("panel_rounds", 4), ("comm_streams", 2)]
 
 
 def test_a_slower_candidate_never_replaces_a_faster_incumbent_whatever_it_exposes():
@@ -68,10 +76,12 @@ def test_small_collective_latency_vetoes_a_setting_that_only_speeds_up_the_filte
             return {"seconds": 0.0588, "exposed_ms": 41.7, "small_collective_us": 950.0 if lat2_us > 1000 else 50.0}
         return measure
     base = {"panel_cols": 256, "panel_rounds": 4, "comm_streams": 1}
-    best, table = A.tune(base, 5, script2(19000.0))
+    best, table = A.tune(base, 5, script2(19000.0), streams=True)
     assert best["comm_streams"] == 1 and table[-1]["setting"]["comm_streams"] == 2 and not table[-1]["kept"]
-    best, table = A.tune(base, 5, script2(60.0))
+    best, table = A.tune(base, 5, script2(60.0), streams=True)
     assert best["comm_streams"] == 2 and table[-1]["kept"]
+    best, table = A.tune(base, 5, script2(60.0), streams=False)                 # the default: not even tried
+    assert best["comm_streams"] == 1 and all(r["setting"]["comm_streams"] == 1 for r in table)
     assert A.cost({"seconds": 0.05, "exposed_ms": 0, "small_collective_us": 1000.0}) == pytest.approx(0.05 + A.SMALL_PER_PRODUCT * 1e-3)
 
 
