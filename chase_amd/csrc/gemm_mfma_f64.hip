@@ -140,7 +140,7 @@ struct GemmArgs {
     double* slabs;
     int glds_ok;                                     // operands are 16-byte addressable: direct global -> LDS copies allowed
     // 3M kernels: plane of the V-side operand sums br + bi in the kernel's own LDS image - per column tile bn and K step kt one
-    // 4 KB block [8 k][64 columns] of doubles at S + (bn * s_nkt + kt) * 512 (splane_kernel writes it before the launch)
+    // 4 KB block [4 k pairs][64 columns][2] of doubles at S + (bn * s_nkt + kt) * 512 (splane_kernel writes it before the launch)
     const double* S; int s_nkt;
     double alpha_re, alpha_im, beta_re, beta_im;
 };
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
             } else if constexpr (CPLX && M3 && CHASE_M3_SPLANE) {
                 // 3M software pipeline, round 6: V-side operand sums from the precomputed plane p.S.
                 //   * LDS: the three 24 KB stages + a RING OF TWO 4 KB stages for the plane = 80 KB (two workgroups still fit
-                //     the CU's 160 KB).  S(kt) lives in ring stage kt & 1, image [8 k][64 columns] of doubles, brought in by ONE
+                //     the CU's 160 KB).  S(kt) lives in ring stage kt & 1, image [4 k pairs][64 columns][2] doubles, brought in by ONE
                 //     more global -> LDS copy per wave and K step (1 KB of the 4 KB block each, linear: the plane is stored in
                 //     this image).  S(kt + 2) is requested right after the mid-step barrier of step kt (all reads of S(kt)
                 //     have completed by then), BEFORE the copies of tile kt + 3, so that the counted vmcnt of the next step
@@ -588,7 +588,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                     ssrc += 4096;
                     s_issue ^= 1;
                 };
-                const int npre = min(nfull, C_::STAGES);
+#ifndef CHASE_M3_DEPTH
+#define CHASE_M3_DEPTH 2            // K steps a tile is requested ahead of its first use (1: experiment, see profiles/r06_*)
+#endif
+                constexpr bool DEPTH1 = (CHASE_M3_DEPTH == 1);
+                const int npre = min(nfull, DEPTH1 ? 2 : C_::STAGES);
                 issue_s(); issue();                                            // S(0), T(0)
                 if (npre > 1) { issue_s(); issue(); }                          // S(1), T(1)
                 if (npre > 2) issue();                                         // T(2)
@@ -611,9 +615,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                 // soff = this lane's byte offset of the ring stage being READ NEXT, toggled (one 32-bit xor) at every mid-step
                 // barrier - ring base 72 KB and stage size 4 KB: bit 12 selects the stage, the lane part stays below 2 KB
                 static_assert(((C_::STAGES * C_::STAGE_UNITS * 16) & 4096) == 0, "ring base must have bit 12 clear");
-                unsigned soff = (unsigned)(C_::STAGES * C_::STAGE_UNITS * 16) + (unsigned)(q * 512 + c16 * 8);
+                // image of a ring stage: [4 k pairs][64 columns][k even, k odd] doubles - the 32 lanes (c16, q = 0 / 1) of one half
+                // of a ds_read_b64 then read 256 contiguous bytes (all 64 banks once; the plain [8 k][64 columns] image was a
+                // two-way conflict, SQ_LDS_BANK_CONFLICT 1.07e10 cycles per launch)
+                unsigned soff = (unsigned)(C_::STAGES * C_::STAGE_UNITS * 16) + (unsigned)((q >> 1) * 1024 + c16 * 16 + (q & 1) * 8);
                 auto ld_s = [&](int ch, int j) __attribute__((always_inline)) -> double {
-                    return *(const double*)((const char*)lds + soff + ch * 2048 + j * 128);
+                    return *(const double*)((const char*)lds + soff + ch * 2048 + j * 256);
                 };
                 d2_t aC[TM], bF[TN];
                 double sS[TN];
@@ -669,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                     cluster(st, 1, yes, no, no);                               // chunk 0 of tile kt, prefetching its chunk 1
                     // my reads of stage st and of its ring stage are complete, my copies of tile kt+1 and of its plane block
                     // have landed; tile kt+2 (requested one step ago) may stay in flight
-                    if (decltype(fill_t_c)::value || kt + 2 < nfull)
+                    if (!DEPTH1 && (decltype(fill_t_c)::value || kt + 2 < nfull))
                         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
                     else
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -677,21 +684,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                     asm volatile("" ::: "memory");
                     soff ^= 4096u;                                             // the other ring stage: tile kt+1's sums
                     __builtin_amdgcn_sched_barrier(0);
-                    cluster(stn, 0, yes, fill_t_c, fill_s_c, st);              // chunk 1 of tile kt (+ the copies)
+                    // (DEPTH1: the tile requested here is kt+2, into the stage BEHIND st, free since the previous step)
+                    cluster(stn, 0, yes, fill_t_c, fill_s_c, DEPTH1 ? (st == 0 ? C_::STAGES - 1 : st - 1) : st);   // chunk 1 of tile kt (+ the copies)
                 };
                 int kt = 0;
                 // steady state, three K steps per trip: the stage indices are compile-time constants, so every LDS address is a
                 // loop-invariant register plus an immediate offset (the ring stage of the sums: one xor per K step)
+                constexpr int AHEAD = DEPTH1 ? 2 : C_::STAGES;                 // the tile a step requests: kt + AHEAD
                 if constexpr (C_::STAGES == 3) {
-                    for (; kt + 2 + C_::STAGES < nfull; kt += 3) {
+                    for (; kt + 2 + AHEAD < nfull; kt += 3) {
                         kstep(kt, 0, yes, yes);
                         kstep(kt + 1, 1, yes, yes);
                         kstep(kt + 2, 2, yes, yes);
                     }
                 }
                 int st = 0;                                                    // kt is a multiple of STAGES here
-                for (; kt + C_::STAGES < nfull; ++kt) { kstep(kt, st, yes, yes); st = (st + 1 == C_::STAGES) ? 0 : st + 1; }
-                if (kt + 2 < nfull)                   { kstep(kt, st, no, yes);  st = (st + 1 == C_::STAGES) ? 0 : st + 1; ++kt; }
+                for (; kt + AHEAD < nfull; ++kt) { kstep(kt, st, yes, yes); st = (st + 1 == C_::STAGES) ? 0 : st + 1; }
+                if (!DEPTH1 && kt + 2 < nfull)        { kstep(kt, st, no, yes);  st = (st + 1 == C_::STAGES) ? 0 : st + 1; ++kt; }
                 for (; kt + 1 < nfull; ++kt)          { kstep(kt, st, no, no);   st = (st + 1 == C_::STAGES) ? 0 : st + 1; }
                 cluster(st, 1, yes, no, no);                                   // last tile: nothing to publish or prefetch after it
                 __builtin_amdgcn_sched_barrier(0);
@@ -983,8 +992,8 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(const double* __restri
 }
 
 // The plane of V-side operand sums of a 3M launch (GemmArgs::S): for column tile bn (columns col0 = bn * bn_cols .. + 63, clamped
-// to the last valid column like the kernel's own B copies) and K step kt the block S[(bn * nkt + kt) * 512 + kk * 64 + c] =
-// re + im of B[k = 8 kt + kk, col0 + c].  One workgroup per (64 k, column tile): B is read along k (1 KB per wave instruction),
+// to the last valid column like the kernel's own B copies) and K step kt the 4 KB block at S + (bn * nkt + kt) * 512, laid out
+// [k pair][column][k even, k odd]: element (kk >> 1) * 128 + 2 c + (kk & 1) = re + im of B[k = 8 kt + kk, col0 + c].  One workgroup per (64 k, column tile): B is read along k (1 KB per wave instruction),
 // transposed through LDS, written along c (512 B per wave instruction).  2.7 GB read + 1.3 GB written at config 4's full width:
 // < 0.1 % of the product it precedes.
 __global__ __launch_bounds__(256) void splane_kernel(const double* __restrict__ B, long ldb, int n, int k, int bn_cols, int nkt,
@@ -1001,10 +1010,11 @@ __global__ __launch_bounds__(256) void splane_kernel(const double* __restrict__ 
         sm[kl][c] = v;
     }
     __syncthreads();
+    // one 16-byte store per (k pair, column): a wave writes 1 KB contiguous
     #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int kl = 4 * it + (t >> 6), c = t & 63, kk = k0 + kl;
-        if (kk < k) S[((size_t)bn * nkt + (kk >> 3)) * 512 + (kk & 7) * 64 + c] = sm[kl][c];
+    for (int it = 0; it < 8; ++it) {
+        const int kp = 4 * it + (t >> 6), c = t & 63, kk = k0 + 2 * kp;          // k is a multiple of 8 for every 3M launch
+        if (kk < k) *(d2_t*)(S + ((size_t)bn * nkt + (kk >> 3)) * 512 + ((kk & 7) >> 1) * 128 + c * 2) = d2_t{sm[2 * kp][c], sm[2 * kp + 1][c]};
     }
 }
 // bytes of the plane for an m x n x k piece in column tiles of bn_cols (0: whole tiles)
