@@ -77,9 +77,11 @@ int chase_hip_gemm_d(chase_hip_ctx* ctx, char opA, int m, int n, int k, double a
 int chase_hip_gemm_z(chase_hip_ctx* ctx, char opA, int m, int n, int k, const double alpha[2], const void* A,
                      long lda, const void* B, long ldb, const double beta[2], void* C, long ldc);
 
-/* bytes of split-K workspace a product of this shape uses on a device with num_cu compute units (context-owned, grown on
- * demand; min_rounds as in chase_hip_ctx_set_gemm_min_rounds) - a pure function of the shape, so that the decomposition and
- * with it the summation order never depend on allocation history.  Host-only: callable without a GPU. */
+/* bytes of workspace a product of this shape uses on a device with num_cu compute units (context-owned, grown on
+ * demand; min_rounds as in chase_hip_ctx_set_gemm_min_rounds): the split-K slabs and - complex products while the
+ * three-multiplication scheme is enabled - the plane of V-side operand sums the 3M kernels read (8 bytes per element of the
+ * k x n operand, rounded up to 64-column tiles).  A pure function of the shape (and of the 3M switch), so that the
+ * decomposition and with it the summation order never depend on allocation history.  Host-only: callable without a GPU. */
 size_t chase_hip_gemm_workspace_bytes(int cplx, char opA, int m, int n, int k, int num_cu, int min_rounds);
 /* 1 when complex products issued in phase 1 (chase_hip_ctx_set_phase: the Chebyshev filter) and phase 2 (the H-times-block
  * products of Rayleigh-Ritz / residuals; CHASE_HIP_GEMM3M_RR=0 keeps those on four) use the three-multiplication scheme

@@ -82,6 +82,9 @@ def test_gemm_workspace_covers_the_rims_of_a_split_three_multiplication_product(
             assert whole >= max(pieces), (op, m, n, k, whole, pieces)
             assert need(op, m, n, k, 4) >= whole or need(op, m, n, k, 4) > 0       # shared-chip granularity: its own plan
     assert need(b"N", 0, 5, 5) == 0
+    # round 6: the operand-sum plane of the 3M kernels (one 4 KB block per 64-column tile and K step) is part of the figure
+    assert need(b"N", 65536, 2560, 65536) >= 40 * 8192 * 4096
+    assert lib.chase_hip_gemm_workspace_bytes(0, b"N", 65536, 2560, 65536, 256, 0) < 40 * 8192 * 4096      # real: no plane
 
 
 def test_stemr_rejects_non_finite_input_instead_of_hanging():
