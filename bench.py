@@ -416,13 +416,13 @@ def attach_replay(out, workload):
     """The compute side of the multi-GPU solve as measured by the single-rank replay (bench.py --replay-rank, a SEPARATE run on
     one GPU, recorded in profiles/): T_rank per grid and the speed-up bound it implies.  Context for the scaling series this
     line starts; not measured in this run and labelled so."""
-    path = os.path.join(ROOT, "profiles", "r05_replay_cfg4.json")
+    path = os.path.join(ROOT, "profiles", "r06_replay_cfg4.json")
     if workload != "cfg4" or not os.path.exists(path):
         return
     try:
         rec = json.load(open(path))
         out["multi_gpu_compute_side"] = {
-            "source": "profiles/r05_replay_cfg4.json: `bench.py --replay-rank 4x2,2x2,2x1` - ONE rank of each grid replaying the "
+            "source": "profiles/r06_replay_cfg4.json: `bench.py --replay-rank 4x2,2x2,2x1` - ONE rank of each grid replaying the "
                       "taped call sequence of a real single-GPU solve on a loopback grid (no communication), NOT measured in this run",
             "single_gpu_solve_seconds": rec["single_gpu"]["solve_seconds"],
             "T_rank_seconds": {r["grid"]: r["T_rank_seconds"] for r in rec["replays"]},
