@@ -1,5 +1,6 @@
 """Parity of every hot-path kernel (through the C ABI) against the CPU oracle / numpy on seeded inputs. GPU only."""
 import ctypes as C
+import os
 import math
 import numpy as np
 import pytest
@@ -260,6 +261,36 @@ def test_potrf_and_trsm(ctx, cplx, n):
     dA2 = ctx.array(A2)
     info = lib.chase_hip_potrf_upper(ctx.h, int(cplx), n, dA2.ptr, n)
     assert info == k + 1
+
+
+def test_three_multiplication_products_keep_their_bits_across_rounds(ctx):
+    """Round 6 rebuilt the 3M filter loop (V-side operand sums from a precomputed plane, another MFMA order, another LDS layout)
+    under the condition that NOTHING changes numerically: the plane holds the same IEEE sums, the accumulators are independent.
+    tests/golden/gemm3m_hashes.json holds the 64-bit content hashes of 26 products (whole tiles, ragged and uniform-ragged
+    widths, K-split tails, rims cut off as 4M products, both ops, phases 1 and 2) that round 2-5's loop and round 6's produced
+    identically on one device; the inputs are device-generated from fixed seeds, so the hashes pin the kernels' bits from now on."""
+    import json
+    from chase_amd.capi import lib
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gemm3m_hashes.json")))["rows"]
+    assert len(gold) == 26
+    try:
+        for g in gold:
+            if g["m"] * g["n"] * g["k"] > 3e11:                  # the two N = 16384 x 2560 products: 0.2 s each, once is enough
+                if g["phase"] == 2:
+                    continue
+            op, m, n, k = g["op"], g["m"], g["n"], g["k"]
+            ra = (m, k) if op == "N" else (k, m)
+            dA = ctx.empty(ra, np.complex128); dB = ctx.empty((k, n), np.complex128); dC = ctx.empty((m, n), np.complex128)
+            for (d, r, c, seed) in ((dA, ra[0], ra[1], 1), (dB, k, n, 2), (dC, m, n, 3)):
+                assert lib.chase_hip_fill_normal(ctx.h, 1, r, c, d.ptr, r, 0, 0, r, seed) == 0
+            lib.chase_hip_ctx_set_phase(ctx.h, g["phase"])
+            ctx.gemm(op, m, n, k, 0.5 - 0.25j, dA.ptr, ra[0], dB.ptr, k, 0.25 + 0.5j, dC.ptr, m, True)
+            h = ctx.hash64(dC.ptr, m, n, m, True)
+            for a in (dA, dB, dC):
+                a.free()
+            assert "%016x" % h == g["hash"], (g, "%016x" % h)
+    finally:
+        lib.chase_hip_ctx_set_phase(ctx.h, 0)
 
 
 @pytest.mark.parametrize("cplx", [False, True])
