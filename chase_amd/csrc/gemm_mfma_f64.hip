@@ -114,7 +114,7 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
 // column tiles.  Measured at N = 65536, n = 2560 (profiles/r02_tile_order.txt): GR = 2 and 4 are 0.9 % faster than GR = 1,
 // GR = 8 is no faster and moves MORE bytes through the fabric (L2 misses: workgroups that share an H panel stay in step
 // only while they were dispatched together) - the launch is bound by MFMA issue, not by the 1.7-2.5 TB/s of L2 fills.
-// Default GR = 2 (CHASE_HIP_TILE_GROUP overrides).
+// Default GR = 2, 4 for long launches with many column tiles (launch_gemm_part; CHASE_HIP_TILE_GROUP overrides).
 __host__ __device__ __forceinline__ void tile_coords(int t, int gm, int gn, int GR, int& bm, int& bn)
 {
     const int gsz = GR * gn;
@@ -1167,8 +1167,16 @@ static int launch_gemm_part(hipStream_t st, int m, int n, int k, const double* a
     a.A = A; a.B = B; a.C = C; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.m = m; a.n = n; a.k = k;
     a.gm = (m + C_::BM - 1) / C_::BM; a.gn = (n + bn_cols - 1) / bn_cols;
     a.bn_cols = bn_cols;
-    static const int group_rows = [] { const char* e = getenv("CHASE_HIP_TILE_GROUP"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
-    a.group_rows = group_rows;
+    // Row panels per group of the tile order (tile_coords): 2; FOUR for launches of many rounds with many column tiles (round 6).
+    // With the plane-fed 3M loop the workgroups that share panels stay in step, so a 4 x 16 patch of tiles per XCD (256 KB of
+    // unique operands per K step instead of 416 KB) really is served by the L2: 0.89 instead of 1.31 TB through the fabric for
+    // the full-width config-4 launch, the same time on a device that holds its clock (873 vs 875 ms) and 2 % less on one that
+    // does not under this load (877 vs 892-898 ms: profiles/r06_tile_group.txt).  Short launches and the 256-column panels of the
+    // grid pipeline (4 column tiles) are 2.5 % SLOWER with 4, hence the rule - a function of the shape alone (the order decides
+    // which tiles form the K-split tail, i.e. the summation order, which must not depend on the device).
+    // CHASE_HIP_TILE_GROUP=<n> fixes it for every launch.
+    static const int group_env = [] { const char* e = getenv("CHASE_HIP_TILE_GROUP"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : v; }();
+    a.group_rows = group_env > 0 ? group_env : ((a.gn >= 16 && (long)a.gm * a.gn >= 16L * 2 * num_cu) ? 4 : 2);
     a.alpha_re = alpha[0]; a.alpha_im = CPLX ? alpha[1] : 0.0;
     a.beta_re = beta[0];   a.beta_im = CPLX ? beta[1] : 0.0;
     const int nkt = (k + C_::BK - 1) / C_::BK;
