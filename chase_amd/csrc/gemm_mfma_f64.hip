@@ -54,6 +54,11 @@
 #ifndef CHASE_M3_SPLANE
 #define CHASE_M3_SPLANE 1
 #endif
+// K steps a tile of the plane-fed loop is requested ahead of its first use: 2 (three LDS stages in flight); 1 = experiment of round 6
+// (tiles one step ahead like the plane: neither faster nor slower on any device tried, profiles/r06_tile_group.txt)
+#ifndef CHASE_M3_DEPTH
+#define CHASE_M3_DEPTH 2
+#endif
 
 namespace chase_hip {
 
@@ -588,9 +593,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                     ssrc += 4096;
                     s_issue ^= 1;
                 };
-#ifndef CHASE_M3_DEPTH
-#define CHASE_M3_DEPTH 2            // K steps a tile is requested ahead of its first use (1: experiment, see profiles/r06_*)
-#endif
                 constexpr bool DEPTH1 = (CHASE_M3_DEPTH == 1);
                 const int npre = min(nfull, DEPTH1 ? 2 : C_::STAGES);
                 issue_s(); issue();                                            // S(0), T(0)
