@@ -639,7 +639,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p)
                     constexpr bool fill_s = decltype(fill_s_c)::value;
                     #pragma unroll
                     for (int i = 0; i < TM; ++i) {
+#ifdef CHASE_DIAG_NO_SA
+                        // diagnostic build (timing only, results wrong on purpose): what would a launch gain if the H-side operand sums
+                        // cost nothing (profiles/r06_dropped_with_data.txt)
+                        const double sa = aC[i].x;
+#else
                         const double sa = OPA_C ? aC[i].x - aC[i].y : aC[i].x + aC[i].y;
+#endif
                         #pragma unroll
                         for (int j = 0; j < TN; ++j) {
                             if (!RAGGED || j < jv) {                           // ragged tile: groups past n carry no MFMAs
