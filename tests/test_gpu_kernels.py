@@ -263,6 +263,45 @@ def test_potrf_and_trsm(ctx, cplx, n):
     assert info == k + 1
 
 
+def test_plane_fed_3m_loop_on_random_shapes(ctx):
+    """Round 6's 3M loop has its own prologue / epilogue cases (1, 2, 3, 4+ K steps; the plane ring's two stages; ragged and
+    uniform-ragged column tiles; K-split tails; leading dimensions larger than the block; column offsets into B and C): 40 seeded
+    random shapes with m a multiple of 128 and k of 8 (the shapes that take the three-multiplication kernels as they stand), both ops,
+    alpha / beta complex, against numpy to a few ulp of sum |a||b| - and the surroundings of C untouched."""
+    from chase_amd.capi import lib, gemm_counters
+    rng = np.random.default_rng(606)
+    lib.chase_hip_ctx_set_phase(ctx.h, 1)
+    try:
+        for t in range(40):
+            m = 128 * int(rng.integers(1, 9))
+            k = 8 * int(rng.choice([1, 2, 3, 4, 5, 7, 16, 33, 64, 130]))
+            n = int(rng.choice([1, 15, 16, 17, 40, 63, 64, 65, 100, 128, 133, 200]))
+            op = "N" if t % 2 == 0 else "C"
+            rounds = 4 if t % 5 == 0 else 0
+            lib.chase_hip_ctx_set_gemm_min_rounds(ctx.h, rounds)
+            pa, pb, pc = int(rng.integers(0, 3)) * 2, int(rng.integers(0, 3)), int(rng.integers(0, 5))
+            A = rnd(rng, ((m if op == "N" else k) + pa, k if op == "N" else m), True)
+            B, Cm = rnd(rng, (k + pb, n + 2), True), rnd(rng, (m + pc, n + 2), True)
+            opA = A[:m, :] if op == "N" else A[:k, :].conj().T
+            alpha, beta = 0.7 - 0.2j, (0.0 if t % 3 == 0 else -0.4 + 0.1j)
+            dA, dB, dC = ctx.array(A), ctx.array(B), ctx.array(Cm)
+            gemm_counters(ctx, 1, reset=True)
+            ctx.gemm(op, m, n, k, alpha, dA.ptr, A.shape[0], dB.offset(1), B.shape[0], beta, dC.offset(1), Cm.shape[0], True)
+            model, execd, _ = gemm_counters(ctx, 1)
+            got = dC.download()
+            ref = Cm.copy()
+            ref[:m, 1:n + 1] = alpha * (opA @ B[:k, 1:n + 1]) + beta * Cm[:m, 1:n + 1]
+            bound = (np.abs(opA) @ np.abs(B[:k, 1:n + 1])).max() + np.abs(Cm).max()
+            assert np.max(np.abs(got - ref)) <= 16 * EPS * bound, (t, op, m, n, k, rounds)
+            assert np.array_equal(got[m:, :], Cm[m:, :]) and np.array_equal(got[:, 0], Cm[:, 0]) and np.array_equal(got[:, n + 1], Cm[:, n + 1])
+            assert execd == pytest.approx(0.75 * model), (t, op, m, n, k)          # it really ran on three multiplications
+            for a in (dA, dB, dC):
+                a.free()
+    finally:
+        lib.chase_hip_ctx_set_gemm_min_rounds(ctx.h, 0)
+        lib.chase_hip_ctx_set_phase(ctx.h, 0)
+
+
 def test_three_multiplication_products_keep_their_bits_across_rounds(ctx):
     """Round 6 rebuilt the 3M filter loop (V-side operand sums from a precomputed plane, another MFMA order, another LDS layout)
     under the condition that NOTHING changes numerically: the plane holds the same IEEE sums, the accumulators are independent.
