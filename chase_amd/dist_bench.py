@@ -307,6 +307,10 @@ def run_distributed(args, probe_only=False):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    # RCCL watchdog of grid.hip: a collective that has not finished this long after it was issued ends the rank with an error
+    # (the library's default, 600 s, is the whole budget of a driver-run bench; the longest legitimate age is one filter call's
+    # queued work: ~40 s at two GPUs)
+    os.environ.setdefault("CHASE_HIP_FABRIC_TIMEOUT_S", "240")
     dist.init_process_group("gloo")
     comm = GlooComm()
     nprow, npcol = cd.grid_shape(world)
@@ -367,6 +371,7 @@ def run_threads(args, nranks):
 
     nprow, npcol = cd.grid_shape(nranks)
     transport = os.environ.get("CHASE_HIP_TRANSPORT", "rccl")
+    os.environ.setdefault("CHASE_HIP_FABRIC_TIMEOUT_S", "240")      # (see run_distributed)
     ndev = max(torch.cuda.device_count(), 1)
     if transport == "rccl" and nranks > ndev:
         raise SystemExit(f"bench: --ranks threads needs one GPU per rank for RCCL ({nranks} ranks, {ndev} devices visible)")
